@@ -1,0 +1,104 @@
+"""Synthetic weights / prompts -- host-side numpy, shared by tests and bench.
+
+Weights follow the reference's init distributions, drawn from numpy `Generator(PCG64(seed))`:
+  * embedding ~ N(0, 1)                                 (layers/models.py:68)
+  * dense kernels ~ truncated normal (+-2 sigma), variance 1/fan_in, sigma corrected by
+    1/0.87962566 as jax.nn.initializers.variance_scaling does      (layers/linears.py:106)
+  * query kernel additionally divided by sqrt(head_dim)            (layers/attentions.py:1900-1904)
+  * norm scales = 1                                                (layers/normalizations.py:40)
+all rounded once to bf16 (round-to-nearest-even).  Keys are the unscanned MaxText tree paths.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import numpy as np
+
+_TRUNC_STD = 0.87962566103423978
+
+
+def f32_to_bf16_bits(x: np.ndarray) -> np.ndarray:
+  u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+  return ((u + (0x7FFF + ((u >> 16) & 1))) >> 16).astype(np.uint16)
+
+
+def bf16_bits_to_f32(h: np.ndarray) -> np.ndarray:
+  return (np.ascontiguousarray(h, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def _trunc_normal(rng: np.random.Generator, n: int) -> np.ndarray:
+  x = rng.standard_normal(n, dtype=np.float32)
+  bad = np.nonzero(np.abs(x) > 2.0)[0]
+  while bad.size:
+    x[bad] = rng.standard_normal(bad.size, dtype=np.float32)
+    bad = bad[np.abs(x[bad]) > 2.0]
+  return x
+
+
+def _dense(rng, shape, fan_in, extra_div=1.0):
+  std = math.sqrt(1.0 / fan_in) / _TRUNC_STD / extra_div
+  n = int(np.prod(shape))
+  return f32_to_bf16_bits(_trunc_normal(rng, n) * np.float32(std)).reshape(shape)
+
+
+def layer_paths(i: int):
+  p = f"params/decoder/layers_{i}/"
+  return {
+      "ln1": p + "pre_self_attention_layer_norm/scale",
+      "q": p + "self_attention/query/kernel",
+      "k": p + "self_attention/key/kernel",
+      "v": p + "self_attention/value/kernel",
+      "o": p + "self_attention/out/kernel",
+      "ln2": p + "mlp/mlp_layer_norm/scale",
+      "wi0": p + "mlp/wi_0/kernel",
+      "wi1": p + "mlp/wi_1/kernel",
+      "wo": p + "mlp/wo/kernel",
+  }
+
+
+def synth_weights(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+  """cfg needs vocab_size, emb_dim, num_query_heads, num_kv_heads, head_dim, mlp_dim, num_decoder_layers."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
+                          cfg.num_decoder_layers)
+  one = f32_to_bf16_bits(np.ones((E,), np.float32))
+  w: Dict[str, np.ndarray] = {}
+  w["params/token_embedder/embedding"] = f32_to_bf16_bits(rng.standard_normal(V * E, dtype=np.float32)).reshape(V, E)
+  for i in range(L):
+    p = layer_paths(i)
+    w[p["ln1"]] = one.copy()
+    w[p["q"]] = _dense(rng, (E, Q, D), E, math.sqrt(D))
+    w[p["k"]] = _dense(rng, (E, KV, D), E)
+    w[p["v"]] = _dense(rng, (E, KV, D), E)
+    w[p["o"]] = _dense(rng, (Q, D, E), Q * D)
+    w[p["ln2"]] = one.copy()
+    w[p["wi0"]] = _dense(rng, (E, F), E)
+    w[p["wi1"]] = _dense(rng, (E, F), E)
+    w[p["wo"]] = _dense(rng, (F, E), F)
+  w["params/decoder/decoder_norm/scale"] = one.copy()
+  w["params/decoder/logits_dense/kernel"] = _dense(rng, (E, V), E)
+  return w
+
+
+def audio_id_to_row(a: np.ndarray) -> np.ndarray:
+  """audio id in [0, 8192) -> embedding row (audio_token_mapping_adjusted.json; extend_tokenizer.py:29-46)."""
+  a = np.asarray(a, np.int64)
+  return np.where(a < 99, 6 + a, 256001 + (a - 99)).astype(np.int32)
+
+
+def synth_prompt(vocab_size: int, prefill_length: int, seed: int = 1234, n_text: int = 46):
+  """SURVEY.md section 8d prompt: [BT] + n_text text ids + [BA] + audio rows, padded to prefill_length.
+  Returns (padded int32[prefill_length], true_length).  Small vocabularies (test models) get uniform ids."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  true_length = int(prefill_length - rng.integers(0, 9)) if prefill_length >= 16 else int(prefill_length)
+  if vocab_size >= 264192:
+    n_audio = true_length - n_text - 2
+    text = rng.integers(106, 256000, size=n_text)
+    audio = audio_id_to_row(rng.integers(0, 8192, size=n_audio))
+    ids = np.concatenate([[264094], text, [264095], audio])
+  else:
+    ids = rng.integers(1, vocab_size, size=true_length)
+  out = np.zeros((prefill_length,), np.int32)
+  out[:true_length] = ids[:true_length]
+  return out, true_length

@@ -1,0 +1,423 @@
+/*
+ * ixt_oracle.c -- CPU ORACLE (test infrastructure, NOT product code).
+ *
+ * A plain-C restatement of the reference's semantic-token LM hot path
+ * (chunked prefill + per-step decode over a paged KV cache) with every
+ * floating-point reduction written in ONE fixed, documented order
+ * ("IXT-F32-v1").  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this file's shared object.
+ *
+ * PARITY UNPINNED: the reference is JAX (not installed here; XLA:CPU's
+ * accumulation order is unspecified by its source) and its tests carry no
+ * numeric golden vectors for this path.  What IS pinned
+ * by the reference's own fixtures: the integer page-manager cases
+ * (tests/inference/page_manager_test.py) and the audio-id mapping tables; see
+ * oracle/oracle.py and tests/.
+ *
+ * Reference lines each function follows (paths relative to /root/reference):
+ *   orc_rmsnorm      MaxText/layers/normalizations.py:57-70
+ *   orc_rope         MaxText/layers/embeddings.py:277-315 (half-split; sin/cos
+ *                    rounded to bf16 before the multiply, :306-307)
+ *   orc_dot_rows     MaxText/layers/linears.py:188-232 (bf16 x bf16, f32 accumulate,
+ *                    bf16 result), kernel cast to bf16 at use (:216)
+ *   attention        MaxText/inference/paged_attention_kernel_v2.py:71-109
+ *                    (ref_ragged_paged_attention: f32 scores, causal offset
+ *                    kv_len-q_len, f32 softmax, P cast to bf16, PV in f32)
+ *   mlp              MaxText/layers/linears.py:425-476 (silu(wi_0 x) * (wi_1 x), :464)
+ *   layer wiring     MaxText/layers/llama2.py:54-165
+ *   embed / head     MaxText/layers/decoders.py:493-534, 537-589; embeddings.py:131-163
+ *   argmax           MaxText/inference_utils.py:74-75 (first max index)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_CL 16   /* chain length (k per fma chain)          */
+#define ORC_NC 8    /* chains per group -> group = 128 k       */
+#define ORC_GL (ORC_CL * ORC_NC)
+#define ORC_SB 4    /* pages per attention super-block         */
+
+typedef struct orc_model {
+  int32_t vocab, emb, nq, nkv, hd, mlp, nlayers;
+  int32_t page, num_pages, max_pages_per_group;
+  float eps;
+  /* weights, all bf16 bit patterns (uint16), row-major */
+  const uint16_t* embedding;          /* [vocab][emb] */
+  const uint16_t* final_norm;         /* [emb] */
+  const uint16_t* logits_w;           /* [emb][vocab] */
+  const uint16_t* const* ln1;         /* [L] -> [emb] */
+  const uint16_t* const* wq;          /* [L] -> [emb][nq*hd] (pre-scaled by 1/sqrt(hd)) */
+  const uint16_t* const* wk;          /* [L] -> [emb][nkv*hd] */
+  const uint16_t* const* wv;          /* [L] -> [emb][nkv*hd] */
+  const uint16_t* const* wo;          /* [L] -> [nq*hd][emb] */
+  const uint16_t* const* ln2;         /* [L] -> [emb] */
+  const uint16_t* const* wi0;         /* [L] -> [emb][mlp] */
+  const uint16_t* const* wi1;         /* [L] -> [emb][mlp] */
+  const uint16_t* const* wout;        /* [L] -> [mlp][emb] */
+  const uint16_t* rope_sin;           /* [max_pos][hd/2] bf16 */
+  const uint16_t* rope_cos;           /* [max_pos][hd/2] bf16 */
+  /* KV pages (oracle-private layout): [L][num_pages][page][nkv][hd] */
+  uint16_t* kpages;
+  uint16_t* vpages;
+} orc_model;
+
+/* ---------------------------------------------------------------- scalars */
+
+static inline float bf2f(uint16_t h) {
+  uint32_t u = ((uint32_t)h) << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static inline uint16_t f2bf(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u); /* quiet NaN */
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+static inline float rbf(float f) { return bf2f(f2bf(f)); }
+
+/* exp in IEEE-only operations (fma/mul/add/rint), identical op sequence to the
+ * device implementation; argument clamped to [-80, 80] so no subnormal or
+ * overflow ever appears. */
+float orc_exp(float x) {
+  x = fminf(fmaxf(x, -80.0f), 80.0f);
+  float n = rintf(x * 1.44269504088896340736f);
+  float r = fmaf(n, -0.693145751953125f, x);            /* ln2 hi (exact in 12 bits) */
+  r = fmaf(n, -1.42860682030941723212e-6f, r);          /* ln2 lo */
+  float p = 1.98412698412698412698e-4f;                 /* 1/5040 */
+  p = fmaf(p, r, 1.38888888888888888889e-3f);           /* 1/720 */
+  p = fmaf(p, r, 8.33333333333333333333e-3f);           /* 1/120 */
+  p = fmaf(p, r, 4.16666666666666666667e-2f);           /* 1/24 */
+  p = fmaf(p, r, 1.66666666666666666667e-1f);           /* 1/6 */
+  p = fmaf(p, r, 0.5f);
+  p = fmaf(p, r, 1.0f);
+  p = fmaf(p, r, 1.0f);
+  int32_t e = (int32_t)n;
+  uint32_t sb = (uint32_t)(e + 127) << 23;
+  float s;
+  memcpy(&s, &sb, 4);
+  return p * s;
+}
+
+/* ---------------------------------------------------------------- rmsnorm */
+/* x: bf16 [E]; scale bf16 [E]; out bf16 [E].
+ * sumsq: chunks of 8 consecutive elements -> fma chain from 0; blocks of 64
+ * chunks -> xor-butterfly (offsets 1,2,4,8,16,32), missing chunks = +0;
+ * blocks summed sequentially from 0. */
+void orc_rmsnorm(const uint16_t* x, const uint16_t* scale, uint16_t* out, int E, float eps) {
+  int nch = E / 8;
+  int nblk = (nch + 63) / 64;
+  float total = 0.0f;
+  for (int b = 0; b < nblk; ++b) {
+    float v[64];
+    for (int l = 0; l < 64; ++l) {
+      int ch = b * 64 + l;
+      float a = 0.0f;
+      if (ch < nch) {
+        for (int j = 0; j < 8; ++j) {
+          float xv = bf2f(x[ch * 8 + j]);
+          a = fmaf(xv, xv, a);
+        }
+      }
+      v[l] = a;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      float t[64];
+      for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ off];
+      memcpy(v, t, sizeof(v));
+    }
+    total = total + v[0];
+  }
+  float mean = total / (float)E;
+  float r = 1.0f / sqrtf(mean + eps);
+  for (int i = 0; i < E; ++i) {
+    float y = rbf(bf2f(x[i]) * r);
+    out[i] = f2bf(y * bf2f(scale[i]));
+  }
+}
+
+/* ---------------------------------------------------------------- rope */
+/* v: bf16 [nh][hd] in place; sin/cos bf16 [hd/2] for this position. */
+void orc_rope(uint16_t* v, int nh, int hd, const uint16_t* sn, const uint16_t* cs) {
+  int half = hd / 2;
+  for (int h = 0; h < nh; ++h) {
+    uint16_t* p = v + (size_t)h * hd;
+    for (int i = 0; i < half; ++i) {
+      float x1 = bf2f(p[i]), x2 = bf2f(p[half + i]);
+      float s = bf2f(sn[i]), c = bf2f(cs[i]);
+      float a = rbf(x1 * c), b = rbf(x2 * s);
+      float d = rbf(x2 * c), e = rbf(x1 * s);
+      p[i] = f2bf(a - b);
+      p[half + i] = f2bf(d + e);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- canonical DOT */
+/* out[r][n] (f32, unrounded) = DOT(x[r][:], W[:, n]); x bf16 [R][K] (row stride ldx),
+ * W bf16 [K][N].  K % 128 == 0.
+ *   chain  c: a = 0; for k in [16c,16c+16): a = fma(x_k, w_kn, a)
+ *   group  g: s = 0; for c in [8g,8g+8):   s = s + chain(c)
+ *   total   : t = 0; for g:                t = t + group(g)              */
+#define ORC_NB 512
+void orc_dot_rows(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, int N, float* out, int ldo) {
+  int nblocks = (N + ORC_NB - 1) / ORC_NB;
+  int ngroups = K / ORC_GL;
+#pragma omp parallel
+  {
+    float* wf = (float*)malloc(sizeof(float) * ORC_CL * ORC_NB);
+    float* ch = (float*)malloc(sizeof(float) * ORC_NB);
+    float* grp = (float*)malloc(sizeof(float) * (size_t)R * ORC_NB);
+    float* tot = (float*)malloc(sizeof(float) * (size_t)R * ORC_NB);
+#pragma omp for schedule(dynamic, 1)
+    for (int nb = 0; nb < nblocks; ++nb) {
+      int n0 = nb * ORC_NB;
+      int nn = N - n0 < ORC_NB ? N - n0 : ORC_NB;
+      for (size_t i = 0; i < (size_t)R * ORC_NB; ++i) tot[i] = 0.0f;
+      for (int g = 0; g < ngroups; ++g) {
+        for (size_t i = 0; i < (size_t)R * ORC_NB; ++i) grp[i] = 0.0f;
+        for (int c = 0; c < ORC_NC; ++c) {
+          int k0 = g * ORC_GL + c * ORC_CL;
+          for (int kk = 0; kk < ORC_CL; ++kk) {
+            const uint16_t* wr = W + (size_t)(k0 + kk) * N + n0;
+            float* wfr = wf + kk * ORC_NB;
+            for (int n = 0; n < nn; ++n) wfr[n] = bf2f(wr[n]);
+          }
+          for (int r = 0; r < R; ++r) {
+            const uint16_t* xr = x + (size_t)r * ldx + k0;
+            for (int n = 0; n < nn; ++n) ch[n] = 0.0f;
+            for (int kk = 0; kk < ORC_CL; ++kk) {
+              float xv = bf2f(xr[kk]);
+              const float* wfr = wf + kk * ORC_NB;
+              for (int n = 0; n < nn; ++n) ch[n] = fmaf(xv, wfr[n], ch[n]);
+            }
+            float* gr = grp + (size_t)r * ORC_NB;
+            for (int n = 0; n < nn; ++n) gr[n] = gr[n] + ch[n];
+          }
+        }
+        for (int r = 0; r < R; ++r) {
+          float* gr = grp + (size_t)r * ORC_NB;
+          float* tr = tot + (size_t)r * ORC_NB;
+          for (int n = 0; n < nn; ++n) tr[n] = tr[n] + gr[n];
+        }
+      }
+      for (int r = 0; r < R; ++r) {
+        float* tr = tot + (size_t)r * ORC_NB;
+        float* o = out + (size_t)r * ldo + n0;
+        for (int n = 0; n < nn; ++n) o[n] = tr[n];
+      }
+    }
+    free(wf); free(ch); free(grp); free(tot);
+  }
+}
+
+/* bf16-rounded variant: out bf16 [R][N] */
+static void dot_rows_bf16(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, int N, uint16_t* out, int ldo, float* scratch) {
+  orc_dot_rows(x, ldx, R, W, K, N, scratch, N);
+  for (int r = 0; r < R; ++r)
+    for (int n = 0; n < N; ++n) out[(size_t)r * ldo + n] = f2bf(scratch[(size_t)r * N + n]);
+}
+
+/* ---------------------------------------------------------------- paged attention */
+/* One query row: q bf16 [nq][hd] (post-RoPE); keys/values of `slot` positions [0, kv_len)
+ * gathered through page_row[pos / page].  out bf16 [nq][hd].  kv_len == 0 -> zeros.
+ *   score   : a = 0; for d: a = fma(q_d, k_jd, a)           (sm_scale = 1.0)
+ *   m       : max_j score
+ *   e_j     : orc_exp(score_j - m)
+ *   l       : per logical page p: s_p = 0; s_p += e_j (j ascending); l = 0; l += s_p
+ *   p_j     : bf16(e_j / l)
+ *   out_d   : page chain a_p = 0; a_p = fma(p_j, v_jd, a_p); super-block of 4 pages
+ *             s = 0; s += a_p; total t = 0; t += s; bf16(t)                        */
+void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int32_t* page_row, int kv_len, uint16_t* out, float* sc /* [kv_len] scratch */) {
+  int hd = m->hd, nkv = m->nkv, nq = m->nq, P = m->page;
+  int grp = nq / nkv;
+  size_t page_elems = (size_t)P * nkv * hd;
+  const uint16_t* kp = m->kpages + (size_t)layer * m->num_pages * page_elems;
+  const uint16_t* vp = m->vpages + (size_t)layer * m->num_pages * page_elems;
+  if (kv_len <= 0) {
+    memset(out, 0, sizeof(uint16_t) * (size_t)nq * hd);
+    return;
+  }
+  int npages = (kv_len + P - 1) / P;
+  for (int h = 0; h < nq; ++h) {
+    int kvh = h / grp;
+    const uint16_t* qh = q + (size_t)h * hd;
+    float mx = -INFINITY;
+    for (int j = 0; j < kv_len; ++j) {
+      const uint16_t* kj = kp + (size_t)page_row[j / P] * page_elems + ((size_t)(j % P) * nkv + kvh) * hd;
+      float a = 0.0f;
+      for (int d = 0; d < hd; ++d) a = fmaf(bf2f(qh[d]), bf2f(kj[d]), a);
+      sc[j] = a;
+      if (a > mx) mx = a;
+    }
+    float l = 0.0f;
+    for (int p = 0; p < npages; ++p) {
+      float s = 0.0f;
+      int j1 = (p + 1) * P < kv_len ? (p + 1) * P : kv_len;
+      for (int j = p * P; j < j1; ++j) {
+        sc[j] = orc_exp(sc[j] - mx);
+        s = s + sc[j];
+      }
+      l = l + s;
+    }
+    for (int j = 0; j < kv_len; ++j) sc[j] = rbf(sc[j] / l);
+    for (int d = 0; d < hd; ++d) {
+      float t = 0.0f;
+      for (int sb = 0; sb * ORC_SB < npages; ++sb) {
+        float s = 0.0f;
+        for (int pp = 0; pp < ORC_SB; ++pp) {
+          int p = sb * ORC_SB + pp;
+          if (p >= npages) break;
+          float a = 0.0f;
+          int j1 = (p + 1) * P < kv_len ? (p + 1) * P : kv_len;
+          const uint16_t* vpage = vp + (size_t)page_row[p] * page_elems;
+          for (int j = p * P; j < j1; ++j) {
+            float vv = bf2f(vpage[((size_t)(j % P) * nkv + kvh) * hd + d]);
+            a = fmaf(sc[j], vv, a);
+          }
+          s = s + a;
+        }
+        t = t + s;
+      }
+      out[(size_t)h * hd + d] = f2bf(t);
+    }
+  }
+}
+
+/* ---------------------------------------------------------------- forward */
+/* R rows processed as one ragged batch (a prefill chunk of one slot, or one decode
+ * token for each of several slots).  Per layer ALL rows' K/V are written to their
+ * pages first, then each row attends to positions [0, pos[r]] of its slot
+ * (causal offset rule of ref_ragged_paged_attention).  Rows with active[r]==0 write
+ * nothing and attend to nothing.
+ *   tokens, slot, pos, active : int32 [R]
+ *   page_map                 : int32 [groups][max_pages_per_group]
+ *   logits_rows              : int32 [n_logits] row indices to unembed
+ *   logits_out               : f32 [n_logits][vocab]  (bf16-rounded values), may be NULL
+ *   argmax_out               : int32 [n_logits]
+ *   hidden_out               : bf16 [R][emb] final pre-norm hidden, may be NULL      */
+void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t* slot, const int32_t* pos,
+                 const int32_t* active, const int32_t* page_map, int n_logits, const int32_t* logits_rows,
+                 float* logits_out, int32_t* argmax_out, uint16_t* hidden_out) {
+  int E = m->emb, hd = m->hd, nq = m->nq, nkv = m->nkv, F = m->mlp, P = m->page;
+  int QN = nq * hd, KN = nkv * hd;
+  size_t page_elems = (size_t)P * nkv * hd;
+  int maxN = QN > F ? QN : F;
+  if (E > maxN) maxN = E;
+  uint16_t* h = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * E);
+  uint16_t* xn = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * E);
+  uint16_t* q = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * QN);
+  uint16_t* k = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * KN);
+  uint16_t* v = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * KN);
+  uint16_t* ao = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * QN);
+  uint16_t* t0 = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * maxN);
+  uint16_t* t1 = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * F);
+  uint16_t* hact = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * F);
+  float* scratch = (float*)malloc(sizeof(float) * (size_t)R * maxN);
+  int max_len = 0;
+  for (int r = 0; r < R; ++r)
+    if (pos[r] + 1 > max_len) max_len = pos[r] + 1;
+
+  for (int r = 0; r < R; ++r) memcpy(h + (size_t)r * E, m->embedding + (size_t)tokens[r] * E, sizeof(uint16_t) * E);
+
+  for (int L = 0; L < m->nlayers; ++L) {
+    for (int r = 0; r < R; ++r) orc_rmsnorm(h + (size_t)r * E, m->ln1[L], xn + (size_t)r * E, E, m->eps);
+    dot_rows_bf16(xn, E, R, m->wq[L], E, QN, q, QN, scratch);
+    dot_rows_bf16(xn, E, R, m->wk[L], E, KN, k, KN, scratch);
+    dot_rows_bf16(xn, E, R, m->wv[L], E, KN, v, KN, scratch);
+    uint16_t* kp = m->kpages + (size_t)L * m->num_pages * page_elems;
+    uint16_t* vp = m->vpages + (size_t)L * m->num_pages * page_elems;
+    for (int r = 0; r < R; ++r) {
+      const uint16_t* sn = m->rope_sin + (size_t)pos[r] * (hd / 2);
+      const uint16_t* cs = m->rope_cos + (size_t)pos[r] * (hd / 2);
+      orc_rope(q + (size_t)r * QN, nq, hd, sn, cs);
+      orc_rope(k + (size_t)r * KN, nkv, hd, sn, cs);
+      if (active[r]) {
+        int32_t pg = page_map[(size_t)slot[r] * m->max_pages_per_group + pos[r] / P];
+        size_t off = (size_t)pg * page_elems + (size_t)(pos[r] % P) * nkv * hd;
+        memcpy(kp + off, k + (size_t)r * KN, sizeof(uint16_t) * KN);
+        memcpy(vp + off, v + (size_t)r * KN, sizeof(uint16_t) * KN);
+      }
+    }
+#pragma omp parallel
+    {
+      float* sc = (float*)malloc(sizeof(float) * (size_t)(max_len > 0 ? max_len : 1));
+#pragma omp for schedule(dynamic, 1)
+      for (int r = 0; r < R; ++r) {
+        int kv_len = active[r] ? pos[r] + 1 : 0;
+        orc_attend_row(m, L, q + (size_t)r * QN, page_map + (size_t)slot[r] * m->max_pages_per_group, kv_len,
+                       ao + (size_t)r * QN, sc);
+      }
+      free(sc);
+    }
+    dot_rows_bf16(ao, QN, R, m->wo[L], QN, E, t0, E, scratch);
+    for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
+    for (int r = 0; r < R; ++r) orc_rmsnorm(h + (size_t)r * E, m->ln2[L], xn + (size_t)r * E, E, m->eps);
+    dot_rows_bf16(xn, E, R, m->wi0[L], E, F, t0, F, scratch);
+    dot_rows_bf16(xn, E, R, m->wi1[L], E, F, t1, F, scratch);
+    for (size_t i = 0; i < (size_t)R * F; ++i) {
+      float a = bf2f(t0[i]);
+      float sg = rbf(1.0f / (1.0f + orc_exp(-a)));
+      float u = rbf(a * sg);
+      hact[i] = f2bf(u * bf2f(t1[i]));
+    }
+    dot_rows_bf16(hact, F, R, m->wout[L], F, E, t0, E, scratch);
+    for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
+  }
+  if (hidden_out) memcpy(hidden_out, h, sizeof(uint16_t) * (size_t)R * E);
+
+  if (n_logits > 0) {
+    uint16_t* y = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)n_logits * E);
+    float* lg = (float*)malloc(sizeof(float) * (size_t)n_logits * m->vocab);
+    for (int i = 0; i < n_logits; ++i)
+      orc_rmsnorm(h + (size_t)logits_rows[i] * E, m->final_norm, y + (size_t)i * E, E, m->eps);
+    orc_dot_rows(y, E, n_logits, m->logits_w, E, m->vocab, lg, m->vocab);
+    for (int i = 0; i < n_logits; ++i) {
+      float* row = lg + (size_t)i * m->vocab;
+      int best = 0;
+      float bv = rbf(row[0]);
+      row[0] = bv;
+      for (int n = 1; n < m->vocab; ++n) {
+        float vv = rbf(row[n]);
+        row[n] = vv;
+        if (vv > bv) { bv = vv; best = n; }
+      }
+      if (argmax_out) argmax_out[i] = best;
+      if (logits_out) memcpy(logits_out + (size_t)i * m->vocab, row, sizeof(float) * m->vocab);
+    }
+    free(y); free(lg);
+  }
+  free(h); free(xn); free(q); free(k); free(v); free(ao); free(t0); free(t1); free(hact); free(scratch);
+}
+
+/* helpers for unit tests */
+void orc_f32_to_bf16(const float* in, uint16_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = f2bf(in[i]);
+}
+void orc_exp_vec(const float* in, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_exp(in[i]);
+}
+void orc_swiglu(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) {
+    float av = bf2f(a[i]);
+    float sg = rbf(1.0f / (1.0f + orc_exp(-av)));
+    float u = rbf(av * sg);
+    out[i] = f2bf(u * bf2f(b[i]));
+  }
+}
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
