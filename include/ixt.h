@@ -1,0 +1,154 @@
+/*
+ * ixt.h -- C ABI of libixt.so: the MI355X (gfx950) hot path of an IndexTTS2-style
+ * semantic-token LM: chunked prompt prefill + per-step audio-token decode over a paged KV cache.
+ *
+ * Boundary rules: plain C, `int` status return (0 = ok, negative = ixt_status,
+ * never throws), device pointers are plain `void*`/typed pointers owned by the caller unless stated,
+ * every compute call takes an explicit hipStream_t (passed as void*), no allocation after
+ * ixt_create/ixt_load_weight, one ctx per GPU, calls on one ctx externally serialised (the reference
+ * engine has no locks either: maxengine.py:550,849,1190-1191,1325-1328).
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference repo).
+ */
+#ifndef IXT_H_
+#define IXT_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum ixt_status {
+  IXT_OK = 0,
+  IXT_ERR_INVALID = -1,      /* bad argument / shape (reference: ValueError)                    */
+  IXT_ERR_HIP = -2,          /* a HIP runtime call failed; see ixt_last_error()                  */
+  IXT_ERR_UNSUPPORTED = -3,  /* configuration outside the built path (reference: NotImplementedError) */
+  IXT_ERR_NOT_LOADED = -4,   /* a weight needed by the call was never loaded                     */
+  IXT_ERR_RANGE = -5         /* slot / length out of range (page_manager.py:529-532)             */
+} ixt_status;
+
+typedef enum ixt_dtype { IXT_BF16 = 0, IXT_F32 = 1 } ixt_dtype;
+
+/* Derived hyper-parameters of MaxText/pyconfig.py:551-644 that shape the path. */
+typedef struct ixt_config {
+  int32_t vocab_size;              /* base.yml:430 */
+  int32_t emb_dim;                 /* base.yml:132 (x scale) */
+  int32_t num_query_heads;         /* base.yml:133 */
+  int32_t num_kv_heads;            /* base.yml:134 */
+  int32_t head_dim;                /* base.yml:137; 64 or 128 */
+  int32_t mlp_dim;                 /* base.yml:135 */
+  int32_t num_decoder_layers;      /* base.yml:136 */
+  float normalization_layer_epsilon; /* base.yml:21 */
+  float rope_min_timescale;        /* base.yml:601 */
+  float rope_max_timescale;        /* base.yml:602 */
+  int32_t max_prefill_predict_length; /* base.yml:528: max rows of one prefill chunk */
+  int32_t max_target_length;       /* base.yml:527 */
+  int32_t max_slots;               /* decode batch = per_device_batch_size (maxengine.py:1455-1458) */
+  int32_t pagedattn_num_pages;     /* base.yml:740 */
+  int32_t pagedattn_tokens_per_page; /* base.yml:741; power of two, 8..64 */
+  int32_t pagedattn_max_pages_per_group; /* base.yml:743 (already derived, > 0) */
+  int32_t use_hip_graph;           /* build knob: capture ixt_generate into one hipGraph */
+} ixt_config;
+
+typedef struct ixt_ctx ixt_ctx;
+
+/* Human-readable text of the last error on this thread. */
+const char* ixt_last_error(void);
+
+/* MaxEngine.__init__ (maxengine.py:107-136): allocates weights storage, page pools, PageState
+ * (page_manager.py:93-126: page 0 permanently reserved), RoPE tables and all workspaces on the
+ * current HIP device. */
+int ixt_create(const ixt_config* cfg, ixt_ctx** out);
+int ixt_destroy(ixt_ctx* ctx);
+
+/* MaxEngine.load_params (maxengine.py:218-271): copy one parameter into the ctx's HBM layout.
+ * `maxtext_path` is the unscanned tree path, e.g. "params/decoder/layers_3/self_attention/query/kernel";
+ * both spellings of the MLP pre-norm are accepted ("mlp/mlp_layer_norm/scale" of linears.py:347-354 and
+ * "post_self_attention_layer_norm/scale" of llama_or_mistral_ckpt.py:449-450).  `dev_ptr` is a device
+ * pointer to a dense row-major array of `shape[ndim]`; IXT_F32 sources are rounded to bf16
+ * (round-to-nearest-even) as linears.py:216 / embeddings.py:154 do at use. */
+int ixt_load_weight(ixt_ctx* ctx, const char* maxtext_path, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, void* stream);
+/* 1 when every parameter of the configured model has been loaded. */
+int ixt_weights_complete(ixt_ctx* ctx);
+
+/* ---- PageState / PageManager (inference/page_manager.py), state lives in HBM ---------------------- */
+/* PageManager.get_initial_page_state (page_manager.py:600-621). */
+int ixt_pages_reset(ixt_ctx* ctx, void* stream);
+/* PageManager.update_prefill_pages (page_manager.py:493-536): release the group, then first-fit reserve
+ * ceil(true_length/page) pages; silently leaves the group empty when resources are short (:305-311). */
+int ixt_pages_reserve(ixt_ctx* ctx, int slot, int true_length, void* stream);
+/* Build extension for chunked prefill over pages (no reference counterpart): keep the
+ * group's pages and grow the allocation to total_length tokens. */
+int ixt_pages_extend(ixt_ctx* ctx, int slot, int total_length, void* stream);
+/* PageManager.update_decode_pages (page_manager.py:331-412,538-566). */
+int ixt_pages_advance(ixt_ctx* ctx, void* stream);
+/* PageManager.release_pages (page_manager.py:568-598). */
+int ixt_pages_release(ixt_ctx* ctx, int slot, void* stream);
+/* MaxEngine.insert's `has_active_page.at[slot].set(True)` (maxengine.py:1189-1191). */
+int ixt_pages_set_active(ixt_ctx* ctx, int slot, int active, void* stream);
+/* Copy the seven PageState fields to HOST arrays (synchronises `stream`):
+ * page_status[num_pages], page_map[max_slots*max_pages_per_group], num_pages_used[max_slots],
+ * sequence_lengths[max_slots], active_page[max_slots], has_active_page[max_slots] (0/1),
+ * active_page_position[max_slots]. */
+int ixt_pages_export(ixt_ctx* ctx, int32_t* page_status, int32_t* page_map, int32_t* num_pages_used,
+                     int32_t* sequence_lengths, int32_t* active_page, uint8_t* has_active_page,
+                     int32_t* active_page_position, void* stream);
+/* Overwrite page_status from a HOST array (test hook for page_manager_test.py:143-160 "no space"). */
+int ixt_pages_import_status(ixt_ctx* ctx, const int32_t* page_status, void* stream);
+
+/* ---- engine-level compute ------------------------------------------------------------------------- */
+/* MaxEngine._prefill_jit body (maxengine.py:400-530) for one chunk of one slot, pages already reserved:
+ * rows = tokens_dev[0..n_tokens) at positions start_pos.., K/V written in place to the slot's pages,
+ * first_token_dev[0] = argmax of the last row's logits (:483-499).  last_logits_dev (f32[vocab]) may be
+ * NULL.  n_tokens is the TRUE length of the chunk (padding rows are never computed). */
+int ixt_prefill_chunk(ixt_ctx* ctx, int slot, const int32_t* tokens_dev, int n_tokens, int start_pos,
+                      int32_t* first_token_dev, float* last_logits_dev, void* stream);
+/* MaxEngine._generate_jit model step (maxengine.py:868-936) for all slots: row b = token tokens_dev[b] at
+ * position pos_dev[b]; rows whose PageState.has_active_page is 0 write no K/V and attend to nothing.
+ * next_tokens_dev[b] = argmax; logits_dev (f32[max_slots*vocab]) may be NULL. */
+int ixt_decode_step(ixt_ctx* ctx, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev,
+                    float* logits_dev, void* stream);
+/* MaxEngine.generate (maxengine.py:838-866): ixt_pages_advance + ixt_decode_step + the state update of
+ * :913-935 in one call (one hipGraph launch when cfg.use_hip_graph): tokens <- new token, next_pos += 1,
+ * generated += 1, result_data[b] = {token, 1, generated} (ResultTokens layout, :915-926). All int32[max_slots]
+ * device arrays except result_data int32[max_slots*3]. */
+int ixt_generate(ixt_ctx* ctx, int32_t* tokens_dev, int32_t* next_pos_dev, int32_t* generated_dev,
+                 int32_t* result_data_dev, float* logits_dev, void* stream);
+
+/* ---- op-level entry points (unit parity against the oracle) ---------------------------------------- */
+/* DenseGeneral.__call__ (linears.py:188-232) in canonical order: out f32[R*N] = x bf16[R*K] . W bf16[K*N]. */
+int ixt_op_dot(ixt_ctx* ctx, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream);
+/* RMSNorm.__call__ (normalizations.py:57-70): out bf16[R*E]. */
+int ixt_op_rmsnorm(ixt_ctx* ctx, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream);
+/* RotaryEmbedding.__call__ (embeddings.py:277-315) in place on x bf16[R][nheads][head_dim], positions int32[R]. */
+int ixt_op_rope(ixt_ctx* ctx, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream);
+/* MlpBlock gate (linears.py:459-464): out = bf16(bf16(silu(a)) * b), n elements. */
+int ixt_op_swiglu(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+/* PagedAttentionOp page writes (paged_attention.py:403-471): k,v bf16[R][nkv][hd] (post-RoPE) into `layer`'s
+ * pages of row_slot[r] at row_pos[r] (rows with row_active[r]==0 skipped). */
+int ixt_op_kv_write(ixt_ctx* ctx, int layer, const uint16_t* k, const uint16_t* v, const int32_t* row_slot,
+                    const int32_t* row_pos, const int32_t* row_active, int R, void* stream);
+/* ref_ragged_paged_attention (paged_attention_kernel_v2.py:71-109): q bf16[R][nq][hd] -> out bf16[R][nq][hd];
+ * row r attends to positions [0, row_pos[r]] of slot row_slot[r] (kv_len - q_len causal offset rule). */
+int ixt_op_paged_attention(ixt_ctx* ctx, int layer, const uint16_t* q, const int32_t* row_slot,
+                           const int32_t* row_pos, const int32_t* row_active, int R, uint16_t* out, void* stream);
+/* Decoder._apply_output_head logits + greedy sampling (decoders.py:566-587, inference_utils.py:74-75):
+ * y bf16[R][emb] (already normed) -> logits f32[R][vocab] (may be NULL), argmax int32[R]. */
+int ixt_op_unembed_argmax(ixt_ctx* ctx, const uint16_t* y, int R, float* logits, int32_t* argmax, void* stream);
+/* Gather a slot's K and V of one layer to dense bf16[length][nkv][hd] device arrays (cache export). */
+int ixt_kv_gather(ixt_ctx* ctx, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream);
+/* RoPE tables (bf16 bit patterns) to HOST arrays [max_target_length][head_dim/2]. */
+int ixt_rope_tables(ixt_ctx* ctx, uint16_t* sin_out, uint16_t* cos_out);
+
+/* Live measurement hook for bench.py: average duration in microseconds of the named kernel family over the
+ * launches made by this ctx since the last ixt_timing_reset, measured with HIP events on the launch stream.
+ * Families: "dot_decode". Returns negative if timing is disabled. */
+int ixt_timing_enable(ixt_ctx* ctx, int enable);
+int ixt_timing_reset(ixt_ctx* ctx);
+int ixt_timing_get(ixt_ctx* ctx, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IXT_H_ */

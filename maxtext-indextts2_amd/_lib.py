@@ -1,0 +1,99 @@
+"""ctypes binding of libixt.so (include/ixt.h).  There is NO fallback: if the HIP library is missing or a
+call fails, the caller gets an exception -- the product path never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libixt.so")
+
+IXT_OK, IXT_ERR_INVALID, IXT_ERR_HIP, IXT_ERR_UNSUPPORTED, IXT_ERR_NOT_LOADED, IXT_ERR_RANGE = 0, -1, -2, -3, -4, -5
+IXT_BF16, IXT_F32 = 0, 1
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_u16p = ctypes.POINTER(ctypes.c_uint16)
+c_u8p = ctypes.POINTER(ctypes.c_uint8)
+c_f32p = ctypes.POINTER(ctypes.c_float)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+vp = ctypes.c_void_p
+
+
+class IxtConfig(ctypes.Structure):
+  _fields_ = [
+      ("vocab_size", ctypes.c_int32), ("emb_dim", ctypes.c_int32), ("num_query_heads", ctypes.c_int32),
+      ("num_kv_heads", ctypes.c_int32), ("head_dim", ctypes.c_int32), ("mlp_dim", ctypes.c_int32),
+      ("num_decoder_layers", ctypes.c_int32), ("normalization_layer_epsilon", ctypes.c_float),
+      ("rope_min_timescale", ctypes.c_float), ("rope_max_timescale", ctypes.c_float),
+      ("max_prefill_predict_length", ctypes.c_int32), ("max_target_length", ctypes.c_int32), ("max_slots", ctypes.c_int32),
+      ("pagedattn_num_pages", ctypes.c_int32), ("pagedattn_tokens_per_page", ctypes.c_int32),
+      ("pagedattn_max_pages_per_group", ctypes.c_int32), ("use_hip_graph", ctypes.c_int32),
+  ]
+
+
+# name -> (restype, argtypes); every symbol include/ixt.h declares
+SIGNATURES = {
+    "ixt_last_error": (ctypes.c_char_p, []),
+    "ixt_create": (ctypes.c_int, [ctypes.POINTER(IxtConfig), ctypes.POINTER(vp)]),
+    "ixt_destroy": (ctypes.c_int, [vp]),
+    "ixt_load_weight": (ctypes.c_int, [vp, ctypes.c_char_p, vp, ctypes.c_int, c_i64p, ctypes.c_int, vp]),
+    "ixt_weights_complete": (ctypes.c_int, [vp]),
+    "ixt_pages_reset": (ctypes.c_int, [vp, vp]),
+    "ixt_pages_reserve": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_extend": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_advance": (ctypes.c_int, [vp, vp]),
+    "ixt_pages_release": (ctypes.c_int, [vp, ctypes.c_int, vp]),
+    "ixt_pages_set_active": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_export": (ctypes.c_int, [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_u8p, c_i32p, vp]),
+    "ixt_pages_import_status": (ctypes.c_int, [vp, c_i32p, vp]),
+    "ixt_prefill_chunk": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "ixt_decode_step": (ctypes.c_int, [vp, vp, vp, vp, vp, vp]),
+    "ixt_generate": (ctypes.c_int, [vp, vp, vp, vp, vp, vp, vp]),
+    "ixt_op_dot": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_op_rmsnorm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_op_rope": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_op_swiglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
+    "ixt_op_kv_write": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp]),
+    "ixt_op_paged_attention": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
+    "ixt_op_unembed_argmax": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
+    "ixt_kv_gather": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
+    "ixt_rope_tables": (ctypes.c_int, [vp, c_u16p, c_u16p]),
+    "ixt_timing_enable": (ctypes.c_int, [vp, ctypes.c_int]),
+    "ixt_timing_reset": (ctypes.c_int, [vp]),
+    "ixt_timing_get": (ctypes.c_int, [vp, ctypes.c_char_p, c_f64p, c_i64p, c_f64p]),
+}
+
+_lib = None
+
+
+class IxtError(RuntimeError):
+  pass
+
+
+def load():
+  """Load libixt.so; raises if it has not been built (run __graft_entry__.build())."""
+  global _lib
+  if _lib is None:
+    if not os.path.exists(LIB_PATH):
+      raise IxtError(f"{LIB_PATH} is missing: build the HIP extension first (python __graft_entry__.py build); "
+                     "there is no CPU fallback")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+      fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+      fn.restype = res
+      fn.argtypes = args
+    _lib = lib
+  return _lib
+
+
+def check(rc: int):
+  """Map ixt_status to the reference's exception conventions (error conventions)."""
+  if rc == IXT_OK:
+    return
+  msg = load().ixt_last_error().decode("utf-8", "replace")
+  if rc in (IXT_ERR_INVALID, IXT_ERR_RANGE):
+    raise ValueError(msg)
+  if rc == IXT_ERR_UNSUPPORTED:
+    raise NotImplementedError(msg)
+  raise IxtError(f"ixt status {rc}: {msg}")

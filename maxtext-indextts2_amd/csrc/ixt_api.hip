@@ -1,0 +1,702 @@
+// ixt_api.hip -- C ABI (include/ixt.h) over the gfx950 kernels in ixt_kernels.h.
+// Host code here is plumbing only: argument checks, HBM ownership, launch geometry, hipGraph capture.
+#include "../../include/ixt.h"
+#include "ixt_kernels.h"
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+static int set_err(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define HIPCHK(expr)                                                                                   \
+  do {                                                                                                 \
+    hipError_t e_ = (expr);                                                                            \
+    if (e_ != hipSuccess) return set_err(IXT_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+extern "C" const char* ixt_last_error(void) { return g_err; }
+
+struct LayerW {
+  bf16_t *ln1, *wqkv, *wo, *ln2, *wi, *wout;
+};
+
+enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER };
+
+struct TimingPair { hipEvent_t a, b; double bytes; };
+
+struct GraphEntry {
+  hipGraphExec_t exec;
+};
+
+struct ixt_ctx {
+  ixt_config cfg;
+  int E, Q, KV, D, F, V, L, P, B, Rmax, NQKV, QN, KN, Tmax, mpg, nsb_max, GQ;
+  // weights
+  bf16_t* embedding = nullptr;
+  bf16_t* final_norm = nullptr;
+  bf16_t* logits_w = nullptr;
+  std::vector<LayerW> layers;
+  std::vector<uint32_t> loaded;  // per layer bitmask; index L = globals (bit0 emb, bit1 norm, bit2 logits)
+  // tables / pools / state
+  bf16_t *rope_sin = nullptr, *rope_cos = nullptr;
+  std::vector<uint16_t> rope_sin_h, rope_cos_h;
+  bf16_t *kpages = nullptr, *vpages = nullptr;
+  size_t layer_page_elems = 0;
+  PageStateDev ps{};
+  // workspaces
+  bf16_t *h_a = nullptr, *h_b = nullptr, *xn = nullptr, *qbuf = nullptr, *ao = nullptr, *hact = nullptr;
+  float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *logits = nullptr;
+  size_t part_floats = 0;
+  int32_t *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_tok = nullptr, *new_tok = nullptr;
+  AttnGeom geom{};
+  // timing
+  bool timing = false;
+  std::vector<TimingPair> tpairs;
+  size_t tused = 0;
+  // graphs keyed by the pointer tuple of ixt_generate
+  std::map<std::string, GraphEntry> graphs;
+  bool capturing = false;
+  std::vector<void*> allocs;
+};
+
+template <typename T>
+static int dmalloc(ixt_ctx* c, T** p, size_t n) {
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, n * sizeof(T) + 256));
+  c->allocs.push_back(q);
+  *p = (T*)q;
+  return IXT_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != IXT_OK) return rc_; } while (0)
+
+static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+
+static void host_rope_tables(const ixt_config& cfg, std::vector<uint16_t>& sn, std::vector<uint16_t>& cs) {
+  // embeddings.py:270-307; every step's rounding is listed in DESIGN.md section 3.
+  const int half = cfg.head_dim / 2, T = cfg.max_target_length;
+  sn.resize((size_t)T * half);
+  cs.resize((size_t)T * half);
+  auto f2bf_h = [](float f) {
+    uint32_t u; memcpy(&u, &f, 4);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  };
+  std::vector<float> ts(half);
+  for (int i = 0; i < half; ++i) {
+    const float frac = (float)(2 * i) / (float)cfg.head_dim;
+    ts[i] = (float)((double)cfg.rope_min_timescale * pow((double)cfg.rope_max_timescale / (double)cfg.rope_min_timescale, (double)frac));
+  }
+  for (int p = 0; p < T; ++p)
+    for (int i = 0; i < half; ++i) {
+      const float ang = (float)p / ts[i];
+      sn[(size_t)p * half + i] = f2bf_h((float)sin((double)ang));
+      cs[(size_t)p * half + i] = f2bf_h((float)cos((double)ang));
+    }
+}
+
+extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
+  if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
+  const ixt_config& c = *cfg;
+  if (c.head_dim != 64 && c.head_dim != 128) return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 or 128 built)", c.head_dim);
+  if (c.emb_dim % IXT_GL || c.mlp_dim % IXT_GL || (c.num_query_heads * c.head_dim) % IXT_GL)
+    return set_err(IXT_ERR_UNSUPPORTED, "emb_dim, mlp_dim and num_query_heads*head_dim must be multiples of %d", IXT_GL);
+  if (c.num_kv_heads <= 0 || c.num_query_heads % c.num_kv_heads) return set_err(IXT_ERR_INVALID, "num_query_heads %% num_kv_heads != 0");
+  const int gq = c.num_query_heads / c.num_kv_heads;
+  if (gq != 1 && gq != 2 && gq != 4) return set_err(IXT_ERR_UNSUPPORTED, "query heads per kv head = %d (1, 2, 4 built)", gq);
+  if (!is_pow2(c.pagedattn_tokens_per_page) || c.pagedattn_tokens_per_page < 8 || c.pagedattn_tokens_per_page > 64)
+    return set_err(IXT_ERR_UNSUPPORTED, "pagedattn_tokens_per_page must be a power of two in [8, 64]");
+  if (c.vocab_size % 8) return set_err(IXT_ERR_UNSUPPORTED, "vocab_size must be a multiple of 8");
+  // page_manager.py:450-473
+  if (c.pagedattn_max_pages_per_group <= 0) return set_err(IXT_ERR_INVALID, "`pagedattn_max_pages_per_group` must be positive.");
+  if (c.pagedattn_max_pages_per_group < (c.max_target_length + c.pagedattn_tokens_per_page - 1) / c.pagedattn_tokens_per_page)
+    return set_err(IXT_ERR_INVALID, "`pagedattn_max_pages_per_group` is insufficient for `max_target_length`.");
+  if (c.pagedattn_num_pages <= 1) return set_err(IXT_ERR_INVALID, "`pagedattn_num_pages` must be greater than 1.");
+  if (c.max_slots <= 0) return set_err(IXT_ERR_INVALID, "`pagedattn_max_page_groups` must be positive.");
+  if (c.max_prefill_predict_length <= 0 || c.max_target_length <= 0) return set_err(IXT_ERR_INVALID, "lengths must be positive");
+
+  ixt_ctx* x = new ixt_ctx();
+  x->cfg = c;
+  x->E = c.emb_dim; x->Q = c.num_query_heads; x->KV = c.num_kv_heads; x->D = c.head_dim; x->F = c.mlp_dim;
+  x->V = c.vocab_size; x->L = c.num_decoder_layers; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
+  x->QN = x->Q * x->D; x->KN = x->KV * x->D; x->NQKV = x->QN + 2 * x->KN; x->Tmax = c.max_target_length;
+  x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
+  x->nsb_max = (x->mpg + IXT_SB - 1) / IXT_SB;
+  x->Rmax = c.max_prefill_predict_length > c.max_slots ? c.max_prefill_predict_length : c.max_slots;
+  const int E = x->E, F = x->F, V = x->V, L = x->L, R = x->Rmax;
+  *out = nullptr;
+  int rc = IXT_OK;
+  auto fail = [&](int code) { ixt_destroy(x); return code; };
+#define A(expr) do { rc = (expr); if (rc != IXT_OK) return fail(rc); } while (0)
+  A(dmalloc(x, &x->embedding, (size_t)V * E));
+  A(dmalloc(x, &x->final_norm, (size_t)E));
+  A(dmalloc(x, &x->logits_w, (size_t)E * V));
+  x->layers.resize(L);
+  x->loaded.assign(L + 1, 0);
+  for (int i = 0; i < L; ++i) {
+    LayerW& w = x->layers[i];
+    A(dmalloc(x, &w.ln1, (size_t)E));
+    A(dmalloc(x, &w.wqkv, (size_t)E * x->NQKV));
+    A(dmalloc(x, &w.wo, (size_t)x->QN * E));
+    A(dmalloc(x, &w.ln2, (size_t)E));
+    A(dmalloc(x, &w.wi, (size_t)E * 2 * F));
+    A(dmalloc(x, &w.wout, (size_t)F * E));
+  }
+  // RoPE tables
+  host_rope_tables(c, x->rope_sin_h, x->rope_cos_h);
+  A(dmalloc(x, &x->rope_sin, x->rope_sin_h.size()));
+  A(dmalloc(x, &x->rope_cos, x->rope_cos_h.size()));
+  if (hipMemcpy(x->rope_sin, x->rope_sin_h.data(), x->rope_sin_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(x->rope_cos, x->rope_cos_h.data(), x->rope_cos_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+    return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
+  // page pools
+  x->layer_page_elems = (size_t)c.pagedattn_num_pages * x->KV * x->P * x->D;
+  A(dmalloc(x, &x->kpages, x->layer_page_elems * L));
+  A(dmalloc(x, &x->vpages, x->layer_page_elems * L));
+  if (hipMemset(x->kpages, 0, x->layer_page_elems * L * 2) != hipSuccess || hipMemset(x->vpages, 0, x->layer_page_elems * L * 2) != hipSuccess)
+    return fail(set_err(IXT_ERR_HIP, "page pool memset failed"));
+  // page state
+  PageStateDev& s = x->ps;
+  s.num_pages = c.pagedattn_num_pages; s.groups = c.max_slots; s.mpg = x->mpg; s.P = x->P;
+  A(dmalloc(x, &s.page_status, (size_t)s.num_pages));
+  A(dmalloc(x, &s.page_map, (size_t)s.groups * s.mpg));
+  A(dmalloc(x, &s.num_pages_used, (size_t)s.groups));
+  A(dmalloc(x, &s.sequence_lengths, (size_t)s.groups));
+  A(dmalloc(x, &s.active_page, (size_t)s.groups));
+  A(dmalloc(x, &s.has_active_page, (size_t)s.groups));
+  A(dmalloc(x, &s.active_page_position, (size_t)s.groups));
+  // workspaces
+  A(dmalloc(x, &x->h_a, (size_t)R * E));
+  A(dmalloc(x, &x->h_b, (size_t)R * E));
+  A(dmalloc(x, &x->xn, (size_t)R * E));
+  A(dmalloc(x, &x->qbuf, (size_t)R * x->QN));
+  A(dmalloc(x, &x->ao, (size_t)R * x->QN));
+  A(dmalloc(x, &x->hact, (size_t)R * F));
+  {
+    // partial slices: SPLIT launches write K/128 slices of [R<=8][N]; FULL launches one slice of [R][N]
+    size_t nmax = (size_t)x->NQKV > (size_t)2 * F ? x->NQKV : (size_t)2 * F;
+    if ((size_t)E > nmax) nmax = E;
+    size_t full = (size_t)R * nmax;
+    size_t gmaxn = 0;
+    auto upd = [&](int K, int N) { size_t v = (size_t)(K / IXT_GL) * N; if (v > gmaxn) gmaxn = v; };
+    upd(E, x->NQKV); upd(x->QN, E); upd(E, 2 * F); upd(F, E);
+    size_t split = gmaxn * (size_t)R;  // generous: any R may use SPLIT
+    x->part_floats = full > split ? full : split;
+    A(dmalloc(x, &x->part, x->part_floats));
+  }
+  A(dmalloc(x, &x->scores, (size_t)R * x->Q * x->Tmax));
+  A(dmalloc(x, &x->pvpart, (size_t)R * x->Q * x->nsb_max * x->D));
+  A(dmalloc(x, &x->logits, (size_t)(x->B > 1 ? x->B : 1) * V));
+  A(dmalloc(x, &x->row_slot, (size_t)R));
+  A(dmalloc(x, &x->row_pos, (size_t)R));
+  A(dmalloc(x, &x->row_active, (size_t)R));
+  A(dmalloc(x, &x->row_tok, (size_t)R));
+  A(dmalloc(x, &x->new_tok, (size_t)R));
+#undef A
+  AttnGeom& g = x->geom;
+  g.nq = x->Q; g.nkv = x->KV; g.hd = x->D; g.P = x->P; g.num_pages = c.pagedattn_num_pages; g.mpg = x->mpg;
+  g.Tmax = x->Tmax; g.nsb_max = x->nsb_max;
+  hipLaunchKernelGGL(k_pages_reset, dim3(1), dim3(64), 0, 0, x->ps);
+  if (hipDeviceSynchronize() != hipSuccess) return fail(set_err(IXT_ERR_HIP, "page state init failed"));
+  *out = x;
+  return IXT_OK;
+}
+
+extern "C" int ixt_destroy(ixt_ctx* c) {
+  if (!c) return IXT_OK;
+  (void)hipDeviceSynchronize();
+  for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+  for (auto& t : c->tpairs) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+  return IXT_OK;
+}
+
+// --------------------------------------------------------------------------------------- weights
+static int copy_param(const void* src, int dtype, bf16_t* dst, int64_t rows, int64_t cols, int64_t ldd, hipStream_t st) {
+  const int64_t n = rows * cols;
+  const int blocks = (int)((n + 255) / 256);
+  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_copy_convert<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, rows, cols, ldd);
+  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_copy_convert<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, rows, cols, ldd);
+  else return set_err(IXT_ERR_INVALID, "dtype %d", dtype);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, void* stream) {
+  if (!c || !path || !dev_ptr || !shape) return set_err(IXT_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::string p(path);
+  if (p.rfind("params/", 0) == 0) p = p.substr(7);
+  int64_t numel = 1;
+  for (int i = 0; i < ndim; ++i) numel *= shape[i];
+  const int E = c->E, F = c->F, V = c->V;
+  auto expect = [&](int64_t n) -> int {
+    if (numel != n) return set_err(IXT_ERR_INVALID, "%s: %lld elements, expected %lld", path, (long long)numel, (long long)n);
+    return IXT_OK;
+  };
+  if (p == "token_embedder/embedding") {
+    TRY(expect((int64_t)V * E)); TRY(copy_param(dev_ptr, dtype, c->embedding, V, E, E, st)); c->loaded[c->L] |= 1; return IXT_OK;
+  }
+  if (p == "decoder/decoder_norm/scale") {
+    TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, c->final_norm, 1, E, E, st)); c->loaded[c->L] |= 2; return IXT_OK;
+  }
+  if (p == "decoder/logits_dense/kernel") {
+    TRY(expect((int64_t)E * V)); TRY(copy_param(dev_ptr, dtype, c->logits_w, E, V, V, st)); c->loaded[c->L] |= 4; return IXT_OK;
+  }
+  int li = -1, consumed = 0;
+  if (sscanf(p.c_str(), "decoder/layers_%d/%n", &li, &consumed) < 1 || li < 0 || li >= c->L || consumed == 0)
+    return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
+  const std::string rest = p.substr(consumed);
+  LayerW& w = c->layers[li];
+  uint32_t& m = c->loaded[li];
+  if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
+  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(copy_param(dev_ptr, dtype, w.wqkv, E, c->QN, c->NQKV, st)); m |= 1u << W_Q; }
+  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(copy_param(dev_ptr, dtype, w.wqkv + c->QN, E, c->KN, c->NQKV, st)); m |= 1u << W_K; }
+  else if (rest == "self_attention/value/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(copy_param(dev_ptr, dtype, w.wqkv + c->QN + c->KN, E, c->KN, c->NQKV, st)); m |= 1u << W_V; }
+  else if (rest == "self_attention/out/kernel") { TRY(expect((int64_t)c->QN * E)); TRY(copy_param(dev_ptr, dtype, w.wo, c->QN, E, E, st)); m |= 1u << W_O; }
+  else if (rest == "mlp/mlp_layer_norm/scale" || rest == "post_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln2, 1, E, E, st)); m |= 1u << W_LN2; }
+  else if (rest == "mlp/wi_0/kernel") { TRY(expect((int64_t)E * F)); TRY(copy_param(dev_ptr, dtype, w.wi, E, F, 2 * F, st)); m |= 1u << W_WI0; }
+  else if (rest == "mlp/wi_1/kernel") { TRY(expect((int64_t)E * F)); TRY(copy_param(dev_ptr, dtype, w.wi + F, E, F, 2 * F, st)); m |= 1u << W_WI1; }
+  else if (rest == "mlp/wo/kernel") { TRY(expect((int64_t)F * E)); TRY(copy_param(dev_ptr, dtype, w.wout, F, E, E, st)); m |= 1u << W_WOUT; }
+  else return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
+  return IXT_OK;
+}
+
+extern "C" int ixt_weights_complete(ixt_ctx* c) {
+  if (!c) return 0;
+  for (int i = 0; i < c->L; ++i)
+    if (c->loaded[i] != (1u << W_PER_LAYER) - 1) return 0;
+  return c->loaded[c->L] == 7 ? 1 : 0;
+}
+
+// --------------------------------------------------------------------------------------- page state
+static int check_slot(ixt_ctx* c, int slot) {
+  if (slot < 0 || slot >= c->B) return set_err(IXT_ERR_RANGE, "PageManager: page_group_id (%d) out of range [0, %d)", slot, c->B);
+  return IXT_OK;
+}
+extern "C" int ixt_pages_reset(ixt_ctx* c, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  hipLaunchKernelGGL(k_pages_reset, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_reserve(ixt_ctx* c, int slot, int true_length, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_slot(c, slot));
+  if (true_length <= 0 || true_length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", true_length, c->Tmax);
+  hipLaunchKernelGGL(k_pages_reserve, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot, true_length, 0);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_extend(ixt_ctx* c, int slot, int total_length, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_slot(c, slot));
+  if (total_length <= 0 || total_length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", total_length, c->Tmax);
+  hipLaunchKernelGGL(k_pages_reserve, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot, total_length, 1);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_advance(ixt_ctx* c, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  hipLaunchKernelGGL(k_pages_advance, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_release(ixt_ctx* c, int slot, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_slot(c, slot));
+  hipLaunchKernelGGL(k_pages_release, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_set_active(ixt_ctx* c, int slot, int active, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_slot(c, slot));
+  hipLaunchKernelGGL(k_pages_set_active, dim3(1), dim3(1), 0, (hipStream_t)stream, c->ps, slot, active ? 1 : 0);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_export(ixt_ctx* c, int32_t* page_status, int32_t* page_map, int32_t* num_pages_used, int32_t* sequence_lengths,
+                                int32_t* active_page, uint8_t* has_active_page, int32_t* active_page_position, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipStreamSynchronize(st));
+  const PageStateDev& s = c->ps;
+  if (page_status) HIPCHK(hipMemcpy(page_status, s.page_status, sizeof(int32_t) * s.num_pages, hipMemcpyDeviceToHost));
+  if (page_map) HIPCHK(hipMemcpy(page_map, s.page_map, sizeof(int32_t) * s.groups * s.mpg, hipMemcpyDeviceToHost));
+  if (num_pages_used) HIPCHK(hipMemcpy(num_pages_used, s.num_pages_used, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+  if (sequence_lengths) HIPCHK(hipMemcpy(sequence_lengths, s.sequence_lengths, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+  if (active_page) HIPCHK(hipMemcpy(active_page, s.active_page, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+  if (active_page_position) HIPCHK(hipMemcpy(active_page_position, s.active_page_position, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+  if (has_active_page) {
+    std::vector<int32_t> tmp(s.groups);
+    HIPCHK(hipMemcpy(tmp.data(), s.has_active_page, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+    for (int i = 0; i < s.groups; ++i) has_active_page[i] = tmp[i] ? 1 : 0;
+  }
+  return IXT_OK;
+}
+extern "C" int ixt_pages_import_status(ixt_ctx* c, const int32_t* page_status, void* stream) {
+  if (!c || !page_status) return set_err(IXT_ERR_INVALID, "null argument");
+  HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+  HIPCHK(hipMemcpy(c->ps.page_status, page_status, sizeof(int32_t) * c->ps.num_pages, hipMemcpyHostToDevice));
+  return IXT_OK;
+}
+
+// --------------------------------------------------------------------------------------- launches
+static int timing_begin(ixt_ctx* c, hipStream_t st, double bytes) {
+  if (!c->timing || c->capturing) return -1;
+  if (c->tused == c->tpairs.size()) {
+    if (c->tpairs.size() >= 16384) return -1;
+    TimingPair t;
+    if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) return -1;
+    c->tpairs.push_back(t);
+  }
+  TimingPair& t = c->tpairs[c->tused];
+  t.bytes = bytes;
+  (void)hipEventRecord(t.a, st);
+  return (int)c->tused++;
+}
+static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
+  if (idx >= 0) (void)hipEventRecord(c->tpairs[idx].b, st);
+}
+
+struct DotResult { int slices; size_t slice_stride; };
+
+template <int RB>
+static void launch_dot_rb(const DotArgs& a, dim3 grid, bool split, bool nt, hipStream_t st) {
+  if (split) {
+    if (nt) hipLaunchKernelGGL((k_dot<RB, true, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_dot<RB, true, false>), grid, dim3(512), 0, st, a);
+  } else {
+    if (nt) hipLaunchKernelGGL((k_dot<RB, false, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_dot<RB, false, false>), grid, dim3(512), 0, st, a);
+  }
+}
+
+// out: f32 [slices][R][N]; force_full: one slice (level-2 sum inside the block)
+static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
+                      bool force_full, hipStream_t st, DotResult* res) {
+  if (K % IXT_GL || N % 8) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 128 or N %% 8");
+  const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
+  const int rowblocks = (R + rb - 1) / rb;
+  const int ntiles = (N + 511) / 512;
+  const int G = K / IXT_GL;
+  bool split = !force_full && (ntiles * rowblocks < 224) && G > 1;
+  if (split && (size_t)G * R * N > out_floats) split = false;
+  if (!split && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+  DotArgs a;
+  a.x = x; a.ldx = ldx; a.w = w; a.K = K; a.N = N; a.R = R; a.out = out; a.groups_per_block = 1;
+  dim3 grid(ntiles, split ? G : 1, rowblocks);
+  const bool nt = rowblocks == 1;
+  const double bytes = (double)K * N * 2.0 + (double)R * K * 2.0 + (double)(split ? G : 1) * R * N * 4.0;
+  const int ti = timing_begin(c, st, bytes);
+  switch (rb) {
+    case 1: launch_dot_rb<1>(a, grid, split, nt, st); break;
+    case 2: launch_dot_rb<2>(a, grid, split, nt, st); break;
+    case 4: launch_dot_rb<4>(a, grid, split, nt, st); break;
+    default: launch_dot_rb<8>(a, grid, split, nt, st); break;
+  }
+  timing_end(c, st, ti);
+  LAUNCHCHK();
+  res->slices = split ? G : 1;
+  res->slice_stride = (size_t)R * N;
+  return IXT_OK;
+}
+
+template <int HD, int GQ>
+static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t* qbuf, bf16_t* out, hipStream_t st) {
+  const AttnGeom& g = c->geom;
+  const int pages_hint = (len_hint + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;
+  int nsplit = (pages_hint + 4 * ppw - 1) / (4 * ppw);
+  if (nsplit < 1) nsplit = 1;
+  ScoreArgs sa;
+  sa.qbuf = qbuf; sa.kpages = c->kpages + (size_t)layer * c->layer_page_elems;
+  sa.row_slot = c->row_slot; sa.row_pos = c->row_pos; sa.row_active = c->row_active; sa.page_map = c->ps.page_map;
+  sa.scores = c->scores; sa.g = g;
+  hipLaunchKernelGGL((k_attn_scores<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, sa);
+  const int nsb_hint = (pages_hint + IXT_SB - 1) / IXT_SB;
+  int nchunk = (nsb_hint + 3) / 4;
+  if (nchunk < 1) nchunk = 1;
+  PvArgs pa;
+  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
+  pa.pvpart = c->pvpart; pa.g = g;
+  const size_t lds = sizeof(float) * ((size_t)g.mpg + 4 * IXT_SB * g.P + 8);
+  hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
+  hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, out, g);
+}
+
+static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t* qbuf, bf16_t* out, hipStream_t st) {
+#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn<HD_, GQ_>(c, layer, R, len_hint, qbuf, out, st); LAUNCHCHK(); return IXT_OK; }
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
+}
+
+static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, const DotResult* part, const bf16_t* h_in, bf16_t* h_out,
+                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st) {
+  RowNormArgs a;
+  a.tokens = tokens; a.embedding = c->embedding; a.part = c->part;
+  a.slices = part ? part->slices : 0; a.slice_stride = part ? part->slice_stride : 0;
+  a.h_in = h_in; a.h_out = h_out; a.scale = scale; a.xn_out = xn_out; a.E = c->E; a.eps = c->cfg.normalization_layer_epsilon;
+  const size_t lds = sizeof(float) * ((size_t)c->E + 64);
+  if (mode == 0) hipLaunchKernelGGL((k_rownorm<0>), dim3(R), dim3(256), lds, st, a);
+  else if (mode == 1) hipLaunchKernelGGL((k_rownorm<1>), dim3(R), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((k_rownorm<2>), dim3(R), dim3(256), lds, st, a);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+// The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
+// Logits are produced for rows [lrow0, lrow0+nl).
+static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, int32_t* argmax_out,
+                        float* logits_out, hipStream_t st) {
+  if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
+  const int E = c->E, F = c->F;
+  DotResult dr;
+  bf16_t* hcur = c->h_a;
+  bf16_t* hnext = c->h_b;
+  TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    TRY(launch_dot(c, c->xn, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
+    {
+      QkvArgs qa;
+      qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
+      qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
+      qa.rope_sin = c->rope_sin; qa.rope_cos = c->rope_cos; qa.qbuf = c->qbuf;
+      qa.kpages = c->kpages + (size_t)l * c->layer_page_elems; qa.vpages = c->vpages + (size_t)l * c->layer_page_elems;
+      qa.g = c->geom;
+      hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
+      LAUNCHCHK();
+    }
+    TRY(launch_attention(c, l, R, len_hint, c->qbuf, c->ao, st));
+    TRY(launch_dot(c, c->ao, c->QN, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
+    TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
+    TRY(launch_dot(c, c->xn, E, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
+    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
+    LAUNCHCHK();
+    TRY(launch_dot(c, c->hact, F, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
+    const bf16_t* next_scale = (l + 1 < c->L) ? c->layers[l + 1].ln1 : c->final_norm;
+    TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st));
+  }
+  if (nl > 0) {
+    if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
+    TRY(launch_dot(c, c->xn + (size_t)lrow0 * E, E, c->logits_w, E, c->V, nl, c->logits, (size_t)nl * c->V, true, st, &dr));
+    hipLaunchKernelGGL(k_round_argmax, dim3(nl), dim3(1024), 0, st, c->logits, c->V, argmax_out, logits_out);
+    LAUNCHCHK();
+  }
+  return IXT_OK;
+}
+
+extern "C" int ixt_prefill_chunk(ixt_ctx* c, int slot, const int32_t* tokens_dev, int n_tokens, int start_pos, int32_t* first_token_dev,
+                                 float* last_logits_dev, void* stream) {
+  if (!c || !tokens_dev || !first_token_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  TRY(check_slot(c, slot));
+  if (n_tokens <= 0 || n_tokens > c->Rmax) return set_err(IXT_ERR_RANGE, "prefill chunk of %d rows (max %d)", n_tokens, c->Rmax);
+  if (start_pos < 0 || start_pos + n_tokens > c->Tmax) return set_err(IXT_ERR_RANGE, "prefill beyond max_target_length");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rows_prefill, dim3((n_tokens + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, slot, start_pos, n_tokens);
+  LAUNCHCHK();
+  return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, first_token_dev, last_logits_dev, st);
+}
+
+static int decode_rows(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, hipStream_t st) {
+  hipLaunchKernelGGL(k_rows_decode, dim3(1), dim3(c->B <= 1024 ? ((c->B + 63) / 64) * 64 : 1024), 0, st, c->row_slot, c->row_pos, c->row_active, c->row_tok,
+                     tokens_dev, pos_dev, c->ps.has_active_page, c->B);
+  LAUNCHCHK();
+  return forward_rows(c, c->B, c->row_tok, c->Tmax, 0, c->B, next_tokens_dev, logits_dev, st);
+}
+
+extern "C" int ixt_decode_step(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, void* stream) {
+  if (!c || !tokens_dev || !pos_dev || !next_tokens_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  if (c->B > 1024) return set_err(IXT_ERR_UNSUPPORTED, "max_slots > 1024");
+  return decode_rows(c, tokens_dev, pos_dev, next_tokens_dev, logits_dev, (hipStream_t)stream);
+}
+
+static int generate_body(ixt_ctx* c, int32_t* tokens_dev, int32_t* next_pos_dev, int32_t* generated_dev, int32_t* result_data_dev, float* logits_dev,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(k_pages_advance, dim3(1), dim3(64), 0, st, c->ps);
+  LAUNCHCHK();
+  TRY(decode_rows(c, tokens_dev, next_pos_dev, c->new_tok, logits_dev, st));
+  hipLaunchKernelGGL(k_generate_epilogue, dim3(1), dim3(((c->B + 63) / 64) * 64), 0, st, c->new_tok, tokens_dev, next_pos_dev, generated_dev, result_data_dev, c->B);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_generate(ixt_ctx* c, int32_t* tokens_dev, int32_t* next_pos_dev, int32_t* generated_dev, int32_t* result_data_dev, float* logits_dev,
+                            void* stream) {
+  if (!c || !tokens_dev || !next_pos_dev || !generated_dev || !result_data_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  if (c->B > 1024) return set_err(IXT_ERR_UNSUPPORTED, "max_slots > 1024");
+  hipStream_t st = (hipStream_t)stream;
+  if (!c->cfg.use_hip_graph || c->timing) return generate_body(c, tokens_dev, next_pos_dev, generated_dev, result_data_dev, logits_dev, st);
+  if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
+  char key[160];
+  snprintf(key, sizeof(key), "%p/%p/%p/%p/%p", (void*)tokens_dev, (void*)next_pos_dev, (void*)generated_dev, (void*)result_data_dev, (void*)logits_dev);
+  auto it = c->graphs.find(key);
+  if (it == c->graphs.end()) {
+    // capture on a private stream so the caller's stream state is untouched
+    hipStream_t cs;
+    HIPCHK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal));
+    c->capturing = true;
+    int rc = generate_body(c, tokens_dev, next_pos_dev, generated_dev, result_data_dev, logits_dev, cs);
+    c->capturing = false;
+    hipError_t e = hipStreamEndCapture(cs, &graph);
+    if (rc != IXT_OK || e != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      (void)hipStreamDestroy(cs);
+      return rc != IXT_OK ? rc : set_err(IXT_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    GraphEntry ge;
+    e = hipGraphInstantiate(&ge.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    (void)hipStreamDestroy(cs);
+    if (e != hipSuccess) return set_err(IXT_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    if (c->graphs.size() >= 8) {
+      for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+      c->graphs.clear();
+    }
+    it = c->graphs.emplace(std::string(key), ge).first;
+  }
+  HIPCHK(hipGraphLaunch(it->second.exec, st));
+  return IXT_OK;
+}
+
+// --------------------------------------------------------------------------------------- op-level
+__global__ void k_sum_slices(const float* part, int slices, size_t stride, float* out, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float t = 0.0f;
+  for (int s = 0; s < slices; ++s) t = t + part[(size_t)s * stride + i];
+  out[i] = t;
+}
+
+extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream) {
+  if (!c || !x || !w || !out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  DotResult dr;
+  if ((size_t)R * N <= c->part_floats) {
+    TRY(launch_dot(c, x, K, w, K, N, R, c->part, c->part_floats, false, st, &dr));
+    const size_t n = (size_t)R * N;
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
+    LAUNCHCHK();
+    return IXT_OK;
+  }
+  return launch_dot(c, x, K, w, K, N, R, out, (size_t)R * N, true, st, &dr);
+}
+
+extern "C" int ixt_op_rmsnorm(ixt_ctx* c, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream) {
+  if (!c || !x || !scale || !out || R <= 0 || E % 8) return set_err(IXT_ERR_INVALID, "bad argument");
+  RowNormArgs a{};
+  a.h_in = x; a.h_out = nullptr; a.scale = scale; a.xn_out = out; a.E = E; a.eps = c->cfg.normalization_layer_epsilon;
+  hipLaunchKernelGGL((k_rownorm<2>), dim3(R), dim3(256), sizeof(float) * ((size_t)E + 64), (hipStream_t)stream, a);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_rope(ixt_ctx* c, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream) {
+  if (!c || !x || !pos || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_rope, dim3(R, nheads), dim3(c->D / 2), 0, (hipStream_t)stream, x, pos, c->rope_sin, c->rope_cos, nheads, c->D);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_swiglu(ixt_ctx* c, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
+  if (!c || !a || !b || !out || n <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_swiglu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_kv_write(ixt_ctx* c, int layer, const uint16_t* k, const uint16_t* v, const int32_t* row_slot, const int32_t* row_pos,
+                               const int32_t* row_active, int R, void* stream) {
+  if (!c || !k || !v || layer < 0 || layer >= c->L || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_kv_write, dim3(R, c->KV), dim3(c->D), 0, (hipStream_t)stream, k, v, row_slot, row_pos, row_active, c->ps.page_map,
+                     c->kpages + (size_t)layer * c->layer_page_elems, c->vpages + (size_t)layer * c->layer_page_elems, c->geom);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_paged_attention(ixt_ctx* c, int layer, const uint16_t* q, const int32_t* row_slot, const int32_t* row_pos,
+                                      const int32_t* row_active, int R, uint16_t* out, void* stream) {
+  if (!c || !q || !out || layer < 0 || layer >= c->L || R <= 0 || R > c->Rmax) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(c->row_slot, row_slot, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->row_pos, row_pos, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, st));
+  HIPCHK(hipMemcpyAsync(c->row_active, row_active, sizeof(int32_t) * R, hipMemcpyDeviceToDevice, st));
+  return launch_attention(c, layer, R, c->Tmax, q, out, st);
+}
+
+extern "C" int ixt_op_unembed_argmax(ixt_ctx* c, const uint16_t* y, int R, float* logits, int32_t* argmax, void* stream) {
+  if (!c || !y || !argmax || R <= 0 || R > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "bad argument");
+  if (!(c->loaded[c->L] & 4)) return set_err(IXT_ERR_NOT_LOADED, "logits_dense/kernel not loaded");
+  hipStream_t st = (hipStream_t)stream;
+  DotResult dr;
+  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, c->logits, (size_t)R * c->V, true, st, &dr));
+  hipLaunchKernelGGL(k_round_argmax, dim3(R), dim3(1024), 0, st, c->logits, c->V, argmax, logits);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_kv_gather(ixt_ctx* c, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream) {
+  if (!c || !k_out || !v_out || layer < 0 || layer >= c->L || length <= 0 || length > c->Tmax) return set_err(IXT_ERR_INVALID, "bad argument");
+  TRY(check_slot(c, slot));
+  hipLaunchKernelGGL(k_kv_gather, dim3(length, c->KV), dim3(c->D), 0, (hipStream_t)stream, c->kpages + (size_t)layer * c->layer_page_elems,
+                     c->vpages + (size_t)layer * c->layer_page_elems, c->ps.page_map, slot, c->geom, k_out, v_out);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_rope_tables(ixt_ctx* c, uint16_t* sin_out, uint16_t* cos_out) {
+  if (!c || !sin_out || !cos_out) return set_err(IXT_ERR_INVALID, "null argument");
+  memcpy(sin_out, c->rope_sin_h.data(), c->rope_sin_h.size() * 2);
+  memcpy(cos_out, c->rope_cos_h.data(), c->rope_cos_h.size() * 2);
+  return IXT_OK;
+}
+
+// --------------------------------------------------------------------------------------- timing
+extern "C" int ixt_timing_enable(ixt_ctx* c, int enable) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  c->timing = enable != 0;
+  return IXT_OK;
+}
+extern "C" int ixt_timing_reset(ixt_ctx* c) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  (void)hipDeviceSynchronize();
+  c->tused = 0;
+  return IXT_OK;
+}
+extern "C" int ixt_timing_get(ixt_ctx* c, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch) {
+  if (!c || !family) return set_err(IXT_ERR_INVALID, "null argument");
+  if (strcmp(family, "dot") != 0 && strcmp(family, "dot_decode") != 0) return set_err(IXT_ERR_INVALID, "unknown family %s", family);
+  HIPCHK(hipDeviceSynchronize());
+  double tot_ms = 0.0, tot_bytes = 0.0;
+  for (size_t i = 0; i < c->tused; ++i) {
+    float ms = 0.0f;
+    HIPCHK(hipEventElapsedTime(&ms, c->tpairs[i].a, c->tpairs[i].b));
+    tot_ms += ms;
+    tot_bytes += c->tpairs[i].bytes;
+  }
+  const double n = c->tused ? (double)c->tused : 1.0;
+  if (avg_us) *avg_us = tot_ms * 1000.0 / n;
+  if (launches) *launches = (int64_t)c->tused;
+  if (bytes_per_launch) *bytes_per_launch = tot_bytes / n;
+  return IXT_OK;
+}

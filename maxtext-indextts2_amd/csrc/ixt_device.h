@@ -1,0 +1,60 @@
+// ixt_device.h -- scalar numerics shared by every kernel ("IXT-F32-v1").
+// Compiled with -ffp-contract=off: a*b+c never fuses; every fused multiply-add is an explicit fmaf.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;
+
+#define IXT_CL 16    // k per fma chain
+#define IXT_NC 8     // chains per group
+#define IXT_GL 128   // k per group (IXT_CL * IXT_NC)
+#define IXT_SB 4     // logical pages per attention super-block
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+
+// round-to-nearest-even; NaN stays NaN
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+// two bf16 packed in one dword: low half = element 0
+__device__ __forceinline__ float bflo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bfhi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pack2(bf16_t lo, bf16_t hi) { return (uint32_t)lo | ((uint32_t)hi << 16); }
+
+// exp from IEEE-only operations; argument clamped to [-80, 80] (no subnormals, no overflow).
+__device__ __forceinline__ float ixt_exp(float x) {
+  x = fminf(fmaxf(x, -80.0f), 80.0f);
+  float n = __builtin_rintf(x * 1.44269504088896340736f);
+  float r = __builtin_fmaf(n, -0.693145751953125f, x);
+  r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+  float p = 1.98412698412698412698e-4f;
+  p = __builtin_fmaf(p, r, 1.38888888888888888889e-3f);
+  p = __builtin_fmaf(p, r, 8.33333333333333333333e-3f);
+  p = __builtin_fmaf(p, r, 4.16666666666666666667e-2f);
+  p = __builtin_fmaf(p, r, 1.66666666666666666667e-1f);
+  p = __builtin_fmaf(p, r, 0.5f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  p = __builtin_fmaf(p, r, 1.0f);
+  int e = (int)n;
+  float s = __uint_as_float((uint32_t)(e + 127) << 23);
+  return p * s;
+}
+
+// MlpBlock gate: bf16(bf16(a * bf16(sigmoid(a))) * b)
+__device__ __forceinline__ bf16_t ixt_swiglu(float a, float b) {
+  float sg = rbf(1.0f / (1.0f + ixt_exp(-a)));
+  float u = rbf(a * sg);
+  return f2bf(u * b);
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// agent-scope (L1-bypassing) accesses for state one wave re-reads after writing it
+__device__ __forceinline__ int ldg_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stg_i32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -1,0 +1,718 @@
+// ixt_kernels.h -- gfx950 kernels of the hot path.  Wave = 64 lanes everywhere.
+//
+// HBM layouts:
+//   weights      bf16 row-major [K][N] (N contiguous): a wave reads 64 lanes x 16 B = 1 KiB of one k-row
+//   K pages      bf16 [layer][page][kv_head][hd/8][tok][8]   (token-minor inside a d-chunk: a wave's
+//                score load is tokens_per_page x 16 B contiguous per page)
+//   V pages      bf16 [layer][page][kv_head][tok][hd]        (a wave's PV load is 256 B contiguous per page)
+//   partials     f32  [slice][row][N]
+#pragma once
+#include "ixt_device.h"
+
+// =====================================================================================================
+// Canonical DOT (DenseGeneral, linears.py:188-232).
+//   grid  = (ceil(N/512), nsplit, ceil(R/RB));  block = 512 threads = 8 waves.
+//   wave w of the block owns chain w of each 128-k group: 16 k-rows x 512 columns, one 16 B load per lane
+//   per k-row, 8 columns x RB rows of f32 accumulators per lane.  The 8 chain results of a group are added
+//   in chain order through LDS (thread t owns column t).  SPLIT: every group sum is written to its own
+//   partial slice (consumer adds slices in order).  !SPLIT: the block walks all groups and adds the group
+//   sums in order itself (one slice).
+// =====================================================================================================
+struct DotArgs {
+  const bf16_t* x;   // [R][K], row stride ldx
+  int ldx;
+  const bf16_t* w;   // [K][N]
+  int K, N, R;
+  float* out;        // [slices][R][N]
+  int groups_per_block;  // SPLIT: groups handled by one block (blockIdx.y picks the range)
+};
+
+template <int RB, bool SPLIT, bool NT>
+__global__ __launch_bounds__(512) void k_dot(DotArgs a) {
+  constexpr int RH = RB < 4 ? RB : 4;  // rows exchanged through LDS per pass
+  __shared__ float xs[IXT_GL * RB];
+  __shared__ float red[8 * RH * 512];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int n0 = blockIdx.x * 512;
+  const int nl = n0 + lane * 8;
+  const bool col_ok = nl < a.N;
+  const int r0 = blockIdx.z * RB;
+  const int G = a.K / IXT_GL;
+  int g_begin = 0, g_end = G;
+  if (SPLIT) {
+    g_begin = blockIdx.y * a.groups_per_block;
+    g_end = min(G, g_begin + a.groups_per_block);
+  }
+  float tot[RB];
+#pragma unroll
+  for (int r = 0; r < RB; ++r) tot[r] = 0.0f;
+
+  for (int g = g_begin; g < g_end; ++g) {
+    // ---- stage x[r0..r0+RB)[g*128 .. +128) as f32, layout xs[k][RB]
+    for (int i = tid; i < IXT_GL * RB; i += 512) {
+      int r = i % RB, k = i / RB;
+      float v = 0.0f;
+      if (r0 + r < a.R) v = bf2f(a.x[(size_t)(r0 + r) * a.ldx + g * IXT_GL + k]);
+      xs[i] = v;
+    }
+    // ---- this wave's 16 weight rows
+    u32x4 wv[IXT_CL];
+    const int kbase = g * IXT_GL + wave * IXT_CL;
+    if (col_ok) {
+      const bf16_t* wp = a.w + (size_t)kbase * a.N + nl;
+#pragma unroll
+      for (int kk = 0; kk < IXT_CL; ++kk) {
+        const u32x4* p = reinterpret_cast<const u32x4*>(wp + (size_t)kk * a.N);
+        if (NT) {
+          wv[kk] = __builtin_nontemporal_load(p);
+        } else {
+          wv[kk] = *p;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < IXT_CL; ++kk) wv[kk] = u32x4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    float acc[RB][8];
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[r][j] = 0.0f;
+#pragma unroll
+    for (int kk = 0; kk < IXT_CL; ++kk) {
+      float wf[8];
+      wf[0] = bflo(wv[kk].x); wf[1] = bfhi(wv[kk].x);
+      wf[2] = bflo(wv[kk].y); wf[3] = bfhi(wv[kk].y);
+      wf[4] = bflo(wv[kk].z); wf[5] = bfhi(wv[kk].z);
+      wf[6] = bflo(wv[kk].w); wf[7] = bfhi(wv[kk].w);
+      const float* xk = xs + (wave * IXT_CL + kk) * RB;
+#pragma unroll
+      for (int r = 0; r < RB; ++r) {
+        float xv = xk[r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
+      }
+    }
+    // ---- add the 8 chains of the group in chain order (thread tid owns column n0+tid)
+#pragma unroll
+    for (int hh = 0; hh < RB / RH; ++hh) {
+      if (hh > 0) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        float* dst = red + ((wave * RH + r) * 512) + lane * 8;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dst[j] = acc[hh * RH + r][j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int c = 0; c < IXT_NC; ++c) s = s + red[(c * RH + r) * 512 + tid];
+        if (SPLIT) {
+          if (r0 + hh * RH + r < a.R && n0 + tid < a.N)
+            a.out[((size_t)g * a.R + r0 + hh * RH + r) * a.N + n0 + tid] = s;
+        } else {
+          tot[hh * RH + r] = tot[hh * RH + r] + s;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!SPLIT) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r)
+      if (r0 + r < a.R && n0 + tid < a.N) a.out[(size_t)(r0 + r) * a.N + n0 + tid] = tot[r];
+  }
+}
+
+// =====================================================================================================
+// Row kernel: (optional) sum of partial slices + residual, then RMSNorm (normalizations.py:57-70).
+//   MODE 0: h = embedding[token[r]]                         (decoders.py:493-534, embeddings.py:154)
+//   MODE 1: h = bf16(h_in + bf16(sum_slices part))          (llama2.py:127, :157)
+//   MODE 2: h = h_in                                        (norm only)
+//   xn = bf16(bf16(h * rsqrt(mean(h^2)+eps)) * scale) when scale != nullptr.
+// grid = R, block = 256, dynamic LDS = E floats + 64 floats.
+// =====================================================================================================
+struct RowNormArgs {
+  const int32_t* tokens;
+  const bf16_t* embedding;
+  const float* part; int slices; size_t slice_stride;  // floats between slices
+  const bf16_t* h_in;
+  bf16_t* h_out;
+  const bf16_t* scale;
+  bf16_t* xn_out;
+  int E; float eps;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* hrow = smem;            // [E]
+  float* blk = smem + a.E;       // [<=64]
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int E = a.E, nch = E / 8, nblk = (nch + 63) / 64;
+  const bf16_t* src = nullptr;
+  if (MODE == 0) src = a.embedding + (size_t)a.tokens[r] * E;
+  if (MODE == 1 || MODE == 2) src = a.h_in + (size_t)r * E;
+  for (int it = 0; it * 4 < nblk; ++it) {
+    const int b = it * 4 + wave;
+    const int ch = b * 64 + lane;
+    float v = 0.0f;
+    if (b < nblk && ch < nch) {
+      const u32x4 hv = *reinterpret_cast<const u32x4*>(src + ch * 8);
+      float h[8] = {bflo(hv.x), bfhi(hv.x), bflo(hv.y), bfhi(hv.y), bflo(hv.z), bfhi(hv.z), bflo(hv.w), bfhi(hv.w)};
+      if (MODE == 1) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = 0.0f;
+        for (int s = 0; s < a.slices; ++s) {
+          const float* p = a.part + (size_t)s * a.slice_stride + (size_t)r * E + ch * 8;
+          const float4 p0 = *reinterpret_cast<const float4*>(p);
+          const float4 p1 = *reinterpret_cast<const float4*>(p + 4);
+          o[0] = o[0] + p0.x; o[1] = o[1] + p0.y; o[2] = o[2] + p0.z; o[3] = o[3] + p0.w;
+          o[4] = o[4] + p1.x; o[5] = o[5] + p1.y; o[6] = o[6] + p1.z; o[7] = o[7] + p1.w;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[j] = rbf(h[j] + rbf(o[j]));
+      }
+      if (MODE != 2 || a.h_out != nullptr) {
+        if (a.h_out != nullptr) {
+          u32x4 ov;
+          ov.x = pack2(f2bf(h[0]), f2bf(h[1])); ov.y = pack2(f2bf(h[2]), f2bf(h[3]));
+          ov.z = pack2(f2bf(h[4]), f2bf(h[5])); ov.w = pack2(f2bf(h[6]), f2bf(h[7]));
+          *reinterpret_cast<u32x4*>(a.h_out + (size_t)r * E + ch * 8) = ov;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        hrow[ch * 8 + j] = h[j];
+        v = __builtin_fmaf(h[j], h[j], v);
+      }
+    }
+    if (b < nblk) {
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+      if (lane == 0) blk[b] = v;
+    }
+  }
+  __syncthreads();
+  if (a.scale == nullptr) return;
+  float total = 0.0f;
+  for (int b = 0; b < nblk; ++b) total = total + blk[b];
+  const float mean = total / (float)E;
+  const float rs = 1.0f / sqrtf(mean + a.eps);
+  for (int ch = tid; ch < nch; ch += 256) {
+    const u32x4 sv = *reinterpret_cast<const u32x4*>(a.scale + ch * 8);
+    const float sc[8] = {bflo(sv.x), bfhi(sv.x), bflo(sv.y), bfhi(sv.y), bflo(sv.z), bfhi(sv.z), bflo(sv.w), bfhi(sv.w)};
+    bf16_t o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = f2bf(rbf(hrow[ch * 8 + j] * rs) * sc[j]);
+    u32x4 ov;
+    ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+    *reinterpret_cast<u32x4*>(a.xn_out + (size_t)r * E + ch * 8) = ov;
+  }
+}
+
+// =====================================================================================================
+// SwiGLU from partial slices (linears.py:449-464): part is [slices][R][2F] (wi_0 columns then wi_1).
+// grid = (ceil(F/256), R), block 256.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slices, size_t slice_stride, int F,
+                                                      bf16_t* out /*[R][F]*/) {
+  const int f = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (f >= F) return;
+  float a = 0.0f, b = 0.0f;
+  for (int s = 0; s < slices; ++s) {
+    const float* p = part + (size_t)s * slice_stride + (size_t)r * 2 * F;
+    a = a + p[f];
+    b = b + p[F + f];
+  }
+  out[(size_t)r * F + f] = ixt_swiglu(rbf(a), rbf(b));
+}
+
+__global__ __launch_bounds__(256) void k_swiglu(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = ixt_swiglu(bf2f(a[i]), bf2f(b[i]));
+}
+
+// =====================================================================================================
+// Attention, four steps (ref_ragged_paged_attention, paged_attention_kernel_v2.py:71-109).
+// =====================================================================================================
+struct AttnGeom {
+  int nq, nkv, hd, P, num_pages, mpg;   // mpg = max_pages_per_group
+  int Tmax;                             // scores row pitch
+  int nsb_max;                          // super-blocks per row (pvpart pitch)
+};
+
+__device__ __forceinline__ size_t kpage_off(const AttnGeom& g, int page, int kvh, int dchunk, int tok) {
+  return ((((size_t)page * g.nkv + kvh) * (g.hd / 8) + dchunk) * g.P + tok) * 8;
+}
+__device__ __forceinline__ size_t vpage_off(const AttnGeom& g, int page, int kvh, int tok) {
+  return (((size_t)page * g.nkv + kvh) * g.P + tok) * g.hd;
+}
+
+// ---- step 1: slice-sum of the QKV projection, bf16 round, RoPE (embeddings.py:277-315), q -> qbuf,
+//      k/v -> pages (paged_attention.py:446-471).  grid = (R, nq + 2*nkv), block 64.
+struct QkvArgs {
+  const float* part; int slices; size_t slice_stride; int ncols;  // ncols = (nq + 2 nkv) * hd
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active;
+  const int32_t* page_map;
+  const bf16_t* rope_sin; const bf16_t* rope_cos;   // [Tmax][hd/2]
+  bf16_t* qbuf;                                     // [R][nq][hd]
+  bf16_t* kpages; bf16_t* vpages;                   // this layer's pools
+  AttnGeom g;
+};
+
+__global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
+  const int r = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;
+  const AttnGeom& g = a.g;
+  const int half = g.hd / 2;
+  if (i >= half) return;
+  const int col0 = hh * g.hd;
+  float v1 = 0.0f, v2 = 0.0f;
+  for (int s = 0; s < a.slices; ++s) {
+    const float* p = a.part + (size_t)s * a.slice_stride + (size_t)r * a.ncols + col0;
+    v1 = v1 + p[i];
+    v2 = v2 + p[half + i];
+  }
+  v1 = rbf(v1);
+  v2 = rbf(v2);
+  const int pos = a.row_pos[r];
+  const bool is_v = hh >= g.nq + g.nkv;
+  if (!is_v) {
+    const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
+    const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
+    const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
+    const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+    v1 = o1;
+    v2 = o2;
+  }
+  if (hh < g.nq) {
+    bf16_t* q = a.qbuf + ((size_t)r * g.nq + hh) * g.hd;
+    q[i] = f2bf(v1);
+    q[half + i] = f2bf(v2);
+    return;
+  }
+  if (!a.row_active[r]) return;
+  const int page = a.page_map[(size_t)a.row_slot[r] * g.mpg + pos / g.P];
+  const int tok = pos % g.P;
+  if (!is_v) {
+    const int kvh = hh - g.nq;
+    a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
+    a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+  } else {
+    const int kvh = hh - g.nq - g.nkv;
+    bf16_t* v = a.vpages + vpage_off(g, page, kvh, tok);
+    v[i] = f2bf(v1);
+    v[half + i] = f2bf(v2);
+  }
+}
+
+// ---- dense k/v bf16 [R][nkv][hd] -> pages (op-level entry point).  grid = (R, nkv), block = hd.
+__global__ void k_kv_write(const bf16_t* k, const bf16_t* v, const int32_t* row_slot, const int32_t* row_pos,
+                           const int32_t* row_active, const int32_t* page_map, bf16_t* kpages, bf16_t* vpages, AttnGeom g) {
+  const int r = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
+  if (!row_active[r] || d >= g.hd) return;
+  const int pos = row_pos[r];
+  const int page = page_map[(size_t)row_slot[r] * g.mpg + pos / g.P];
+  const int tok = pos % g.P;
+  const size_t src = ((size_t)r * g.nkv + kvh) * g.hd + d;
+  kpages[kpage_off(g, page, kvh, d / 8, tok) + (d & 7)] = k[src];
+  vpages[vpage_off(g, page, kvh, tok) + d] = v[src];
+}
+
+// ---- pages -> dense [len][nkv][hd] (cache export).  grid = (len, nkv), block = hd.
+__global__ void k_kv_gather(const bf16_t* kpages, const bf16_t* vpages, const int32_t* page_map, int slot, AttnGeom g,
+                            bf16_t* k_out, bf16_t* v_out) {
+  const int j = blockIdx.x, kvh = blockIdx.y, d = threadIdx.x;
+  if (d >= g.hd) return;
+  const int page = page_map[(size_t)slot * g.mpg + j / g.P];
+  const int tok = j % g.P;
+  const size_t dst = ((size_t)j * g.nkv + kvh) * g.hd + d;
+  k_out[dst] = kpages[kpage_off(g, page, kvh, d / 8, tok) + (d & 7)];
+  v_out[dst] = vpages[vpage_off(g, page, kvh, tok) + d];
+}
+
+// ---- step 2: scores s_j = chain over d of q_d * k_jd (one fma chain per key, lane = key).
+//      grid = (R, nkv, nsplit), block 256; a wave covers 64/P pages per pass.
+struct ScoreArgs {
+  const bf16_t* qbuf; const bf16_t* kpages;
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
+  float* scores;      // [R][nq][Tmax]
+  AttnGeom g;
+};
+
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_scores(ScoreArgs a) {
+  __shared__ __attribute__((aligned(16))) float qs[GQ * HD];
+  const AttnGeom& g = a.g;
+  const int r = blockIdx.x, kvh = blockIdx.y, sp = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kv_len = a.row_active[r] ? a.row_pos[r] + 1 : 0;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;  // pages per wave pass
+  const int first = (sp * 4) * ppw;
+  if (first >= pages) return;
+  for (int i = tid; i < GQ * HD; i += 256) qs[i] = bf2f(a.qbuf[((size_t)r * g.nq + kvh * GQ) * HD + i]);
+  __syncthreads();
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+  const int stride = gridDim.z * 4;
+  for (int ps = sp * 4 + wave; ps * ppw < pages; ps += stride) {
+    const int pidx = ps * ppw + lane / g.P;
+    const int tok = lane % g.P;
+    const int j = pidx * g.P + tok;
+    if (j >= kv_len) continue;
+    const int page = prow[pidx];
+    const bf16_t* kp = a.kpages + kpage_off(g, page, kvh, 0, tok);
+    u32x4 kv[HD / 8];
+#pragma unroll
+    for (int dc = 0; dc < HD / 8; ++dc) kv[dc] = *reinterpret_cast<const u32x4*>(kp + (size_t)dc * g.P * 8);
+    float acc[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) acc[q] = 0.0f;
+#pragma unroll
+    for (int dc = 0; dc < HD / 8; ++dc) {
+      const float kf[8] = {bflo(kv[dc].x), bfhi(kv[dc].x), bflo(kv[dc].y), bfhi(kv[dc].y),
+                           bflo(kv[dc].z), bfhi(kv[dc].z), bflo(kv[dc].w), bfhi(kv[dc].w)};
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) {
+        const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8);
+        const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8 + 4);
+        float s = acc[q];
+        s = __builtin_fmaf(qa.x, kf[0], s); s = __builtin_fmaf(qa.y, kf[1], s);
+        s = __builtin_fmaf(qa.z, kf[2], s); s = __builtin_fmaf(qa.w, kf[3], s);
+        s = __builtin_fmaf(qb.x, kf[4], s); s = __builtin_fmaf(qb.y, kf[5], s);
+        s = __builtin_fmaf(qb.z, kf[6], s); s = __builtin_fmaf(qb.w, kf[7], s);
+        acc[q] = s;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) a.scores[((size_t)r * g.nq + kvh * GQ + q) * g.Tmax + j] = acc[q];
+  }
+}
+
+// ---- step 3: softmax + PV per super-block.  grid = (R, nkv, ceil(nsb_max/4)), block 256 (4 waves,
+//      one super-block each).  Every block recomputes the row's max / exp / page sums / l (cheap, exact
+//      in the canonical order) and the P of its own 4 super-blocks; lane = (page-in-super-block, d-chunk).
+struct PvArgs {
+  const float* scores; const bf16_t* vpages;
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
+  float* pvpart;      // [R][nq][nsb_max][hd]
+  AttnGeom g;
+};
+
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const AttnGeom& g = a.g;
+  const int r = blockIdx.x, kvh = blockIdx.y, chunk = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int kv_len = a.row_active[r] ? a.row_pos[r] + 1 : 0;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  if (chunk * 4 >= nsb) return;
+  const int maxpages = g.mpg;
+  float* psum = sm;                       // [maxpages]
+  float* pbuf = sm + maxpages;            // [4 super-blocks * 4 pages * P]
+  float* wred = pbuf + 4 * IXT_SB * g.P;  // [8]
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+  constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
+  constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
+  const int j0 = chunk * 4 * IXT_SB * g.P;  // first key of this block's range
+
+  for (int q = 0; q < GQ; ++q) {
+    const int h = kvh * GQ + q;
+    const float* srow = a.scores + ((size_t)r * g.nq + h) * g.Tmax;
+    // max (order independent)
+    float m = -INFINITY;
+    for (int j = tid; j < kv_len; j += 256) m = fmaxf(m, srow[j]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    __syncthreads();  // protects wred / psum / pbuf reuse across q iterations
+    if (lane == 0) wred[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    // exp + page sums: thread p owns logical page p
+    for (int p = tid; p < pages; p += 256) {
+      float s = 0.0f;
+      const int j1 = min((p + 1) * g.P, kv_len);
+      for (int j = p * g.P; j < j1; ++j) {
+        const float e = ixt_exp(srow[j] - m);
+        s = s + e;
+        const int rel = j - j0;
+        if (rel >= 0 && rel < 4 * IXT_SB * g.P) pbuf[rel] = e;
+      }
+      psum[p] = s;
+    }
+    __syncthreads();
+    float l = 0.0f;
+    for (int p = 0; p < pages; ++p) l = l + psum[p];
+    for (int rel = tid; rel < 4 * IXT_SB * g.P; rel += 256)
+      if (j0 + rel < kv_len) pbuf[rel] = rbf(pbuf[rel] / l);
+    __syncthreads();
+    // PV: a wave covers PPW pages at once = PPW/4 super-blocks
+    const int tq = lane / LPP, dc = lane % LPP;
+    if (wave * PPW < 4 * IXT_SB) {
+      const int pass = 0;
+      const int pg_local = wave * PPW + tq;  // 0..15: page within this block's 16-page range
+      const int p = chunk * 4 * IXT_SB + pg_local;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+      if (p < pages) {
+        const int page = prow[p];
+        const bf16_t* vp = a.vpages + vpage_off(g, page, kvh, 0) + dc * 8;
+        const int ntok = min(g.P, kv_len - p * g.P);
+        for (int t = 0; t < ntok; ++t) {
+          const u32x4 vv = *reinterpret_cast<const u32x4*>(vp + (size_t)t * HD);
+          const float pj = pbuf[pg_local * g.P + t];
+          acc[0] = __builtin_fmaf(pj, bflo(vv.x), acc[0]); acc[1] = __builtin_fmaf(pj, bfhi(vv.x), acc[1]);
+          acc[2] = __builtin_fmaf(pj, bflo(vv.y), acc[2]); acc[3] = __builtin_fmaf(pj, bfhi(vv.y), acc[3]);
+          acc[4] = __builtin_fmaf(pj, bflo(vv.z), acc[4]); acc[5] = __builtin_fmaf(pj, bfhi(vv.z), acc[5]);
+          acc[6] = __builtin_fmaf(pj, bflo(vv.w), acc[6]); acc[7] = __builtin_fmaf(pj, bfhi(vv.w), acc[7]);
+        }
+      }
+      // super-block sum: pages 4s..4s+3 live in lane groups tq = 4s'..4s'+3 of this wave
+      const int sbl = tq / IXT_SB;            // super-block within the wave
+      const int base_lane = sbl * IXT_SB * LPP + dc;
+      float sbs[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sbs[j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < IXT_SB; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sbs[j] = sbs[j] + __shfl(acc[j], base_lane + i * LPP, 64);
+      }
+      if (tq % IXT_SB == 0) {
+        const int sb = chunk * 4 + ((pass * 4 + wave) * PPW) / IXT_SB + sbl;
+        if (sb < nsb) {
+          float* dst = a.pvpart + (((size_t)r * g.nq + h) * g.nsb_max + sb) * HD + dc * 8;
+          *reinterpret_cast<float4*>(dst) = make_float4(sbs[0], sbs[1], sbs[2], sbs[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(sbs[4], sbs[5], sbs[6], sbs[7]);
+        }
+      }
+    }
+  }
+}
+
+// ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
+__global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const int32_t* row_pos, const int32_t* row_active,
+                                                      bf16_t* out, AttnGeom g) {
+  const int r = blockIdx.x;
+  const int kv_len = row_active[r] ? row_pos[r] + 1 : 0;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  const int n = g.nq * g.hd;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int h = i / g.hd, d = i % g.hd;
+    float t = 0.0f;
+    for (int sb = 0; sb < nsb; ++sb) t = t + pvpart[(((size_t)r * g.nq + h) * g.nsb_max + sb) * g.hd + d];
+    out[(size_t)r * n + i] = f2bf(t);
+  }
+}
+
+// =====================================================================================================
+// RoPE on dense rows (op-level).  grid = (R, nheads), block = hd/2.
+// =====================================================================================================
+__global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, const bf16_t* rope_cos, int nheads, int hd) {
+  const int r = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd / 2;
+  if (i >= half) return;
+  bf16_t* p = x + ((size_t)r * nheads + h) * hd;
+  const float x1 = bf2f(p[i]), x2 = bf2f(p[half + i]);
+  const float sn = bf2f(rope_sin[(size_t)pos[r] * half + i]), cs = bf2f(rope_cos[(size_t)pos[r] * half + i]);
+  p[i] = f2bf(rbf(x1 * cs) - rbf(x2 * sn));
+  p[half + i] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+}
+
+// =====================================================================================================
+// Greedy sampling (inference_utils.py:74-75): logits f32 [R][V] (unrounded canonical totals) are rounded to
+// bf16 (logits_dot_in_fp32 = False, decoders.py:570) in place, argmax = FIRST index of the maximum.
+// grid = R, block 1024.
+// =====================================================================================================
+__global__ __launch_bounds__(1024) void k_round_argmax(float* logits, int V, int32_t* out_idx, float* logits_copy) {
+  __shared__ float bv[1024];
+  __shared__ int bi[1024];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float* row = logits + (size_t)r * V;
+  float best = -INFINITY;
+  int idx = 0x7fffffff;
+  for (int n = tid; n < V; n += 1024) {
+    const float v = rbf(row[n]);
+    if (logits_copy) logits_copy[(size_t)r * V + n] = v;
+    if (v > best || (v == best && n < idx)) { best = v; idx = n; }
+  }
+  bv[tid] = best; bi[tid] = idx;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) {
+      const float v = bv[tid + s]; const int i2 = bi[tid + s];
+      if (v > bv[tid] || (v == bv[tid] && i2 < bi[tid])) { bv[tid] = v; bi[tid] = i2; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) out_idx[r] = bi[0] == 0x7fffffff ? 0 : bi[0];
+}
+
+// =====================================================================================================
+// Row descriptors and state update.
+// =====================================================================================================
+__global__ void k_rows_prefill(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int slot, int start, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { row_slot[i] = slot; row_pos[i] = start + i; row_active[i] = 1; }
+}
+__global__ void k_rows_decode(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int32_t* row_tok,
+                              const int32_t* tokens, const int32_t* pos, const int32_t* has_active, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) { row_slot[i] = i; row_pos[i] = pos[i]; row_active[i] = has_active[i]; row_tok[i] = tokens[i]; }
+}
+// maxengine.py:913-935
+__global__ void k_generate_epilogue(const int32_t* new_tok, int32_t* tokens, int32_t* next_pos, int32_t* generated,
+                                    int32_t* result, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    tokens[i] = new_tok[i];
+    next_pos[i] = next_pos[i] + 1;
+    const int gnew = generated[i] + 1;
+    generated[i] = gnew;
+    result[i * 3 + 0] = new_tok[i];
+    result[i * 3 + 1] = 1;
+    result[i * 3 + 2] = gnew;
+  }
+}
+
+// =====================================================================================================
+// PageState kernels (inference/page_manager.py), one wave each, state in HBM.
+// =====================================================================================================
+struct PageStateDev {
+  int32_t* page_status;          // [num_pages]
+  int32_t* page_map;             // [groups][mpg]
+  int32_t* num_pages_used;       // [groups]
+  int32_t* sequence_lengths;     // [groups]
+  int32_t* active_page;          // [groups]
+  int32_t* has_active_page;      // [groups] (0/1)
+  int32_t* active_page_position; // [groups]
+  int num_pages, groups, mpg, P;
+};
+
+// lowest index >= 1 with status 0, else -1 (page_manager.py:129-156); whole wave cooperates.
+// Every access is an agent-scope (L1-bypassing) access followed by a wave-level drain, because the
+// same wave re-reads words that its lane 0 has just written.
+__device__ __forceinline__ void wave_drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__device__ int wave_find_free(const int32_t* status, int num_pages, int lane) {
+  for (int base = 0; base < num_pages; base += 64) {
+    const int i = base + lane;
+    const bool free_ = (i >= 1 && i < num_pages) ? (ldg_i32(status + i) == 0) : false;
+    const unsigned long long mask = __ballot(free_);
+    if (mask) return base + __ffsll((long long)mask) - 1;
+  }
+  return -1;
+}
+__device__ int wave_count_free(const int32_t* status, int num_pages, int lane) {
+  int c = 0;
+  for (int base = 0; base < num_pages; base += 64) {
+    const int i = base + lane;
+    const bool free_ = i < num_pages ? (ldg_i32(status + i) == 0) : false;
+    c += __popcll(__ballot(free_));
+  }
+  return c;
+}
+
+__device__ void wave_release_group(PageStateDev s, int g, int lane) {
+  const int nvalid = ldg_i32(s.num_pages_used + g);
+  for (int i = lane; i < s.mpg; i += 64) {
+    const int idx = ldg_i32(s.page_map + (size_t)g * s.mpg + i);
+    if (i < nvalid && idx > 0) stg_i32(s.page_status + idx, 0);
+  }
+  if (lane == 0) {
+    stg_i32(s.num_pages_used + g, 0); stg_i32(s.sequence_lengths + g, 0); stg_i32(s.active_page + g, 0);
+    stg_i32(s.has_active_page + g, 0); stg_i32(s.active_page_position + g, 0);
+  }
+  wave_drain();
+}
+
+__global__ __launch_bounds__(64) void k_pages_reset(PageStateDev s) {
+  const int lane = threadIdx.x;
+  for (int i = lane; i < s.num_pages; i += 64) s.page_status[i] = (i == 0) ? 1 : 0;
+  for (int i = lane; i < s.groups * s.mpg; i += 64) s.page_map[i] = 0;
+  for (int i = lane; i < s.groups; i += 64) {
+    s.num_pages_used[i] = 0; s.sequence_lengths[i] = 0; s.active_page[i] = 0;
+    s.has_active_page[i] = 0; s.active_page_position[i] = 0;
+  }
+}
+__global__ __launch_bounds__(64) void k_pages_release(PageStateDev s, int g) { wave_release_group(s, g, threadIdx.x); }
+
+// release + reserve (page_manager.py:208-328); extend != 0: keep pages, grow to `length` tokens (build extension)
+__global__ __launch_bounds__(64) void k_pages_reserve(PageStateDev s, int g, int length, int extend) {
+  const int lane = threadIdx.x;
+  if (!extend) wave_release_group(s, g, lane);
+  const int need = (length + s.P - 1) / s.P;
+  const int have = extend ? ldg_i32(s.num_pages_used + g) : 0;
+  const int extra = need > have ? need - have : 0;
+  const int nfree = wave_count_free(s.page_status, s.num_pages, lane);
+  if (!(nfree >= extra && need <= s.mpg)) return;
+  for (int i = have; i < need; ++i) {
+    const int nf = wave_find_free(s.page_status, s.num_pages, lane);
+    if (nf >= 0 && lane == 0) {
+      stg_i32(s.page_status + nf, 1);
+      stg_i32(s.page_map + (size_t)g * s.mpg + i, nf);
+      stg_i32(s.num_pages_used + g, ldg_i32(s.num_pages_used + g) + 1);
+    }
+    wave_drain();
+  }
+  if (lane == 0) {
+    stg_i32(s.sequence_lengths + g, length);
+    stg_i32(s.active_page + g, ldg_i32(s.page_map + (size_t)g * s.mpg + need - 1));
+    stg_i32(s.has_active_page + g, 1);
+    stg_i32(s.active_page_position + g, ((length - 1) % s.P + 1) % s.P);
+  }
+}
+
+// page_manager.py:331-412
+__global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
+  const int lane = threadIdx.x;
+  for (int base = 0; base < s.groups; base += 64) {
+    const int g = base + lane;
+    bool needs = false;
+    if (g < s.groups) {
+      const int act = s.has_active_page[g];
+      const int nl = s.sequence_lengths[g] + (act ? 1 : 0);
+      s.sequence_lengths[g] = nl;
+      if (act) s.active_page_position[g] = (nl - 1) % s.P;
+      const int required = (nl + s.P - 1) / s.P;
+      needs = act && required > s.num_pages_used[g] && required <= s.mpg;
+    }
+    unsigned long long mask = __ballot(needs);
+    while (mask) {
+      const int gl = __ffsll((long long)mask) - 1;
+      mask &= mask - 1;
+      const int gg = base + gl;
+      const int nf = wave_find_free(s.page_status, s.num_pages, lane);
+      if (nf >= 0 && lane == 0) {
+        stg_i32(s.page_status + nf, 1);
+        const int used = s.num_pages_used[gg];
+        s.page_map[(size_t)gg * s.mpg + used] = nf;
+        s.num_pages_used[gg] = used + 1;
+        s.active_page[gg] = nf;
+      }
+      wave_drain();
+    }
+  }
+}
+__global__ void k_pages_set_active(PageStateDev s, int g, int v) { s.has_active_page[g] = v; }
+
+// =====================================================================================================
+// load-time helpers
+// =====================================================================================================
+// dst[r*ldd + c] = bf16(src[r*cols + c])
+template <typename T>
+__global__ void k_copy_convert(const T* src, bf16_t* dst, int64_t rows, int64_t cols, int64_t ldd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols, c = i % cols;
+  if constexpr (sizeof(T) == 4) dst[r * ldd + c] = f2bf(src[i]);
+  else dst[r * ldd + c] = src[i];
+}

@@ -1,0 +1,323 @@
+"""MaxEngine over libixt.so -- same method names, argument names and result structures as the reference
+engine (/root/reference/MaxText/maxengine.py:100-1487) for the prefill / insert / generate path, with
+`attention="paged"` semantics.  PyTorch is used for device memory and streams only; all arithmetic is in
+the HIP library.  Thread rule mirrors the reference: one engine per GPU, calls externally serialised.
+
+Differences that a caller can observe (all documented in DESIGN.md section 6):
+  * prefill writes K/V straight into the slot's pages, so `Prefix["cache"]` is a handle, and `insert`
+    is a state copy (the reference's page-copy loop, maxengine.py:1106-1125, is unnecessary);
+  * `decode_state` tensors are updated in place and returned (the reference donates them, :868, :1045);
+  * padding rows (index >= true_length) are never computed;
+  * chunked prefill (`existing_prefix`) extends the slot's pages instead of release+reserve.
+"""
+from __future__ import annotations
+
+import ctypes
+import dataclasses
+import os
+from typing import Any, Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import engine_api
+from . import synth as _synth
+from .inference.page_manager import PageManager, PageState
+
+Params = Any
+Prefix = Dict[str, Any]
+DecodeState = Dict[str, Any]
+
+
+@dataclasses.dataclass
+class ExistingPrefix:
+  """maxengine.py:66-76."""
+  cache: Any
+  common_prefix_tokens: Any
+
+
+class PagedCacheHandle:
+  """Stands where the reference's cache pytree stands: K/V live in the engine's page pools."""
+
+  def __init__(self, engine: "MaxEngine", slot: Optional[int], length: int):
+    self.engine, self.slot, self.length = engine, slot, length
+
+  def gather(self, layer: int):
+    """Dense (k, v) bf16 tensors [length, num_kv_heads, head_dim] of this slot."""
+    return self.engine.gather_kv(layer, self.slot, self.length)
+
+
+def _stream_ptr() -> int:
+  return torch.cuda.current_stream().cuda_stream
+
+
+class MaxEngine(engine_api.Engine):
+  """See module docstring; reference: maxengine.py:100."""
+
+  def __init__(self, config: Any, devices: Any | None = None):
+    if not torch.cuda.is_available():
+      raise _lib.IxtError("MaxEngine needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+    self.config = config
+    self.lib = _lib.load()
+    if config.attention not in ("paged", "autoselected"):
+      raise NotImplementedError(f"attention={config.attention}: this build implements the paged path only")
+    if config.quantization or config.quantize_kvcache:
+      raise NotImplementedError("quantized weights / KV cache are outside the built path")
+    if config.decode_sampling_strategy != "greedy":
+      raise NotImplementedError("only greedy sampling is built (parity is defined on greedy decode)")
+    self.device = torch.device("cuda", torch.cuda.current_device())
+    B = int(config.per_device_batch_size)
+    if B <= 0:
+      raise ValueError("per_device_batch_size must be >= 1")
+    c = _lib.IxtConfig()
+    c.vocab_size, c.emb_dim = config.vocab_size, config.emb_dim
+    c.num_query_heads, c.num_kv_heads, c.head_dim = config.num_query_heads, config.num_kv_heads, config.head_dim
+    c.mlp_dim, c.num_decoder_layers = config.mlp_dim, config.num_decoder_layers
+    c.normalization_layer_epsilon = config.normalization_layer_epsilon
+    c.rope_min_timescale, c.rope_max_timescale = float(config.rope_min_timescale), float(config.rope_max_timescale)
+    c.max_prefill_predict_length, c.max_target_length = config.max_prefill_predict_length, config.max_target_length
+    c.max_slots = B
+    c.pagedattn_num_pages, c.pagedattn_tokens_per_page = config.pagedattn_num_pages, config.pagedattn_tokens_per_page
+    c.pagedattn_max_pages_per_group = config.pagedattn_max_pages_per_group
+    c.use_hip_graph = 1 if config.ixt_use_hip_graph else 0
+    self._ccfg = c
+    self._ctx = ctypes.c_void_p()
+    _lib.check(self.lib.ixt_create(ctypes.byref(c), ctypes.byref(self._ctx)))
+    self._B = B
+    self.page_manager = PageManager(config, engine=self)
+    self.page_state = self.page_manager.get_initial_page_state()
+    self.rng = None
+    self._params_loaded = False
+    self._result = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
+    self._first = torch.zeros((1,), dtype=torch.int32, device=self.device)
+
+  def __del__(self):
+    try:
+      if getattr(self, "_ctx", None) is not None and self._ctx:
+        self.lib.ixt_destroy(self._ctx)
+        self._ctx = None
+    except Exception:  # pylint: disable=broad-except
+      pass
+
+  # ------------------------------------------------------------------ params
+  def load_params(self, *args, params: Optional[Dict[str, Any]] = None, rng: Any = None, **kwargs) -> Params:
+    """maxengine.py:218-271.  `params`: {MaxText tree path: array}; arrays may be torch (bf16/f32), numpy float32 or
+    numpy uint16 (bf16 bit patterns).  With params=None and load_parameters_path == "" the weights are random-init
+    (seed `ixt_synthetic_seed`), as the reference's setup_decode_state does (maxtext_utils.py:917-922)."""
+    if params is None:
+      path = self.config.load_parameters_path
+      if path:
+        params = _load_checkpoint(path)
+      else:
+        params = _synth.synth_weights(self.config, int(self.config.ixt_synthetic_seed))
+    st = _stream_ptr()
+    for name, arr in params.items():
+      t, dtype = _to_device_tensor(arr, self.device)
+      shape = (ctypes.c_int64 * t.dim())(*t.shape)
+      _lib.check(self.lib.ixt_load_weight(self._ctx, name.encode(), ctypes.c_void_p(t.data_ptr()), dtype, shape, t.dim(), ctypes.c_void_p(st)))
+      torch.cuda.current_stream().synchronize()
+      del t
+    if not self.lib.ixt_weights_complete(self._ctx):
+      raise ValueError("load_params: parameter tree is incomplete for the configured model")
+    self._params_loaded = True
+    return {"params": "resident in HBM (libixt)", "engine": id(self)}
+
+  # ------------------------------------------------------------------ prefill
+  def prefill(self, *, params: Params, existing_prefix: Optional[ExistingPrefix] = None, padded_tokens: Any, images: Any = None,
+              true_length: int, sampler: Any = None, rng: Any = None, request_id: Any = None, slot: Optional[int] = None,
+              return_prompt_logp: bool = False) -> Tuple[Prefix, engine_api.ResultTokens]:
+    """maxengine.py:533-574 (+ _prefill_jit :400-530)."""
+    del params, sampler, rng, request_id
+    if images is not None:
+      raise NotImplementedError("multimodal prefill is outside the built path")
+    if return_prompt_logp or self.config.return_log_prob:
+      raise NotImplementedError("log-prob outputs are outside the built path")
+    if slot is None:
+      slot = 0
+    true_length = int(true_length)
+    toks = _as_device_i32(padded_tokens, self.device).reshape(-1)
+    start = 0
+    if existing_prefix is not None:
+      if not self.use_chunked_prefill:
+        raise ValueError("Using chunked prefill is needed for existing_prefix.")
+      start = int(_numel(existing_prefix.common_prefix_tokens))
+    if true_length <= 0 or true_length > toks.numel():
+      raise ValueError(f"true_length ({true_length}) out of range (0, {toks.numel()}]")
+    if start == 0:
+      self.page_state = self.page_manager.update_prefill_pages(page_state=self.page_state, page_group_id=slot, true_length=true_length)
+    else:
+      self.page_state = self.page_manager.extend_prefill_pages(page_state=self.page_state, page_group_id=slot, total_length=start + true_length)
+    V = self.config.vocab_size
+    logits = torch.empty((1, 1, V), dtype=torch.float32, device=self.device)
+    first = torch.empty((1, 1), dtype=torch.int32, device=self.device)
+    _lib.check(self.lib.ixt_prefill_chunk(self._ctx, slot, ctypes.c_void_p(toks.data_ptr()), true_length, start,
+                                          ctypes.c_void_p(first.data_ptr()), ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    generated = torch.zeros((1, 1), dtype=torch.int32, device=self.device)
+    data = torch.cat([first, torch.ones_like(first), generated], dim=1)
+    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=1)
+    next_pos = torch.full((1, 1), start + true_length, dtype=torch.int32, device=self.device)
+    prefix = {
+        "logits": logits,
+        "cache": PagedCacheHandle(self, slot, start + true_length),
+        "next_pos": next_pos,
+        "generated_tokens": generated,
+        "tokens": first,
+        "prompt_logp": None,
+    }
+    return prefix, result
+
+  def prefill_multisampling(self, *args, **kwargs):
+    raise NotImplementedError("prefill_multisampling (maxengine.py:595) is outside the built path (greedy only)")
+
+  def prefill_concat(self, *args, **kwargs):
+    raise NotImplementedError("prefill_concat (maxengine.py:719) packs prompts for the dense cache; not built for pages")
+
+  # ------------------------------------------------------------------ generate
+  def generate(self, params: Params, decode_state: DecodeState, sampler: Any = None, rng: Any = None) -> Tuple[DecodeState, engine_api.ResultTokens]:
+    """maxengine.py:838-936: page advance + one token for all slots + state update, in one library call."""
+    del params, sampler, rng
+    lg = decode_state.get("logits")
+    lg_ptr = ctypes.c_void_p(lg.data_ptr()) if isinstance(lg, torch.Tensor) else None
+    _lib.check(self.lib.ixt_generate(self._ctx, ctypes.c_void_p(decode_state["tokens"].data_ptr()),
+                                     ctypes.c_void_p(decode_state["next_pos"].data_ptr()),
+                                     ctypes.c_void_p(decode_state["generated_tokens"].data_ptr()),
+                                     ctypes.c_void_p(self._result.data_ptr()), lg_ptr, ctypes.c_void_p(_stream_ptr())))
+    result = engine_api.ResultTokens(data=self._result.clone(), tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None,
+                                     samples_per_slot=1)
+    return decode_state, result
+
+  # ------------------------------------------------------------------ insert
+  def insert(self, prefix: Prefix, decode_state: DecodeState, slot: int, request_id: Any = None) -> DecodeState:
+    """maxengine.py:1166-1192 (the cache copy of :1045-1164 is not needed: K/V are already in the slot's pages)."""
+    del request_id
+    if slot < 0 or slot >= self._B:
+      raise ValueError(f"slot {slot} out of range [0, {self._B})")
+    handle = prefix["cache"]
+    if isinstance(handle, PagedCacheHandle) and handle.slot is not None and handle.slot != slot:
+      raise ValueError(f"prefix was prefilled into slot {handle.slot}, cannot insert into slot {slot}: pages are written in place")
+    decode_state["next_pos"][slot] = prefix["next_pos"][0]
+    decode_state["generated_tokens"][slot] = prefix["generated_tokens"][0]
+    decode_state["tokens"][slot] = prefix["tokens"][0]
+    if isinstance(decode_state.get("logits"), torch.Tensor) and prefix.get("logits") is not None:
+      decode_state["logits"][slot] = prefix["logits"][0]
+    _lib.check(self.lib.ixt_pages_set_active(self._ctx, slot, 1, ctypes.c_void_p(_stream_ptr())))
+    return decode_state
+
+  def bulk_insert(self, prefix: Prefix, decode_state: DecodeState, slots: list[int]) -> DecodeState:
+    """maxengine.py:946-1043: one prefix into several slots.  Pages are per slot, so only the slot the prefix was
+    prefilled into can receive it in place."""
+    for s in slots:
+      decode_state = self.insert(prefix, decode_state, s)
+    return decode_state
+
+  def insert_partial(self, *args, **kwargs):
+    raise NotImplementedError("insert_partial (maxengine.py:1206) unpacks prefill_concat results; not built for pages")
+
+  # ------------------------------------------------------------------ state
+  def init_decode_state(self, *args, rng: Any = None, **kwargs) -> DecodeState:
+    """maxengine.py:1370-1453.  `logits` ([B,1,V] f32, 1 MB per slot at V=264192) is materialised only when the caller
+    asks (`materialize_logits=True`); the field is present either way."""
+    del args, rng
+    B = self._B
+    z = lambda: torch.zeros((B, 1), dtype=torch.int32, device=self.device)
+    logits = None
+    if kwargs.get("materialize_logits", False):
+      logits = torch.zeros((B, 1, self.config.vocab_size), dtype=torch.float32, device=self.device)
+    return {"logits": logits, "cache": PagedCacheHandle(self, None, 0), "next_pos": z(), "generated_tokens": z(), "tokens": z()}
+
+  def release_pages(self, slot: int):
+    """maxengine.py:1320-1328."""
+    self.page_state = self.page_manager.release_pages(page_state=self.page_state, page_group_id=slot)
+
+  def gather_kv(self, layer: int, slot: int, length: int):
+    c = self.config
+    k = torch.empty((length, c.num_kv_heads, c.head_dim), dtype=torch.bfloat16, device=self.device)
+    v = torch.empty_like(k)
+    _lib.check(self.lib.ixt_kv_gather(self._ctx, layer, slot, length, ctypes.c_void_p(k.data_ptr()), ctypes.c_void_p(v.data_ptr()),
+                                      ctypes.c_void_p(_stream_ptr())))
+    return k, v
+
+  def get_prefix_destination_sharding(self) -> Any:
+    return None  # single device per engine: nothing to shard (maxengine.py:1330-1337)
+
+  def get_tokenizer(self):
+    raise NotImplementedError("tokenizer plumbing (jetstream token_utils) is outside the built path; pass token ids")
+
+  def build_tokenizer(self, metadata):
+    raise NotImplementedError("tokenizer plumbing (jetstream token_utils) is outside the built path; pass token ids")
+
+  @property
+  def max_concurrent_decodes(self) -> int:
+    return self._B
+
+  @property
+  def max_prefill_length(self) -> int:
+    return int(self.config.max_prefill_predict_length)
+
+  @property
+  def use_chunked_prefill(self) -> bool:
+    return bool(self.config.use_chunked_prefill)
+
+  @property
+  def prefill_chunk_size(self) -> int:
+    return int(self.config.prefill_chunk_size)
+
+  @property
+  def samples_per_slot(self) -> int:
+    return 1
+
+  @property
+  def mesh(self):
+    return None
+
+  @property
+  def colocated_cpus(self) -> None:
+    raise NotImplementedError
+
+
+# ---------------------------------------------------------------------- helpers
+def _numel(x) -> int:
+  if hasattr(x, "numel"):
+    return int(x.numel())
+  return int(np.asarray(x).size)
+
+
+def _as_device_i32(x, device) -> torch.Tensor:
+  if isinstance(x, torch.Tensor):
+    return x.to(device=device, dtype=torch.int32).contiguous()
+  return torch.from_numpy(np.ascontiguousarray(np.asarray(x), dtype=np.int32)).to(device)
+
+
+def _to_device_tensor(arr, device):
+  """-> (contiguous device tensor, ixt_dtype).  uint16 numpy arrays are bf16 bit patterns."""
+  if isinstance(arr, torch.Tensor):
+    if arr.dtype == torch.bfloat16:
+      return arr.to(device).contiguous(), _lib.IXT_BF16
+    if arr.dtype == torch.float32:
+      return arr.to(device).contiguous(), _lib.IXT_F32
+    raise ValueError(f"unsupported parameter dtype {arr.dtype}")
+  a = np.asarray(arr)
+  if a.dtype == np.uint16:
+    t = torch.from_numpy(np.ascontiguousarray(a).view(np.int16)).to(device)
+    return t, _lib.IXT_BF16
+  if a.dtype == np.float32:
+    return torch.from_numpy(np.ascontiguousarray(a)).to(device), _lib.IXT_F32
+  raise ValueError(f"unsupported parameter dtype {a.dtype}")
+
+
+def _load_checkpoint(path: str) -> Dict[str, Any]:
+  """Flat checkpoint keyed by MaxText tree paths: .safetensors or .npz (the reference's Orbax format is not read)."""
+  if path.endswith(".safetensors"):
+    from safetensors.torch import load_file  # pylint: disable=import-outside-toplevel
+    return dict(load_file(path))
+  if path.endswith(".npz"):
+    with np.load(path) as z:
+      return {k: z[k] for k in z.files}
+  raise ValueError(f"load_parameters_path {path}: expected .safetensors or .npz")
+
+
+def create_engine_from_config_flags(config, **kwargs) -> MaxEngine:
+  """maxengine.py:1509."""
+  del kwargs
+  return MaxEngine(config)

@@ -1,0 +1,183 @@
+"""GPU parity, engine level: MaxEngine (HIP) against OracleEngine (CPU) through the reference's call order
+(decode.py:133-184): prefill -> init_decode_state -> insert -> generate loop.  Bar: token ids, logits (f32 bit
+patterns), K/V cache contents and PageState are all bit-exact."""
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+PAGE_FIELDS = ("page_status", "page_map", "num_pages_used", "sequence_lengths", "active_page", "has_active_page", "active_page_position")
+
+
+def assert_pages_equal(eng, orc):
+  st = eng.page_manager.device_state().to_numpy()
+  for f in PAGE_FIELDS:
+    assert np.array_equal(st[f], getattr(orc.page_state, f)), f
+
+
+def run_pair(cfg, weights, prompts, steps, use_graph=True, check_logits=True, chunks=None):
+  """prompts: list of (padded_tokens, true_length) one per slot (len <= batch).  Returns HIP token matrix."""
+  import torch
+  eng, params = H.make_engine(cfg, weights)
+  orc = H.make_oracle(cfg, weights)
+  B = int(cfg.per_device_batch_size)
+  prefixes, oprefixes = [], []
+  for slot, (toks, tl) in enumerate(prompts):
+    if chunks is None:
+      pre, res = eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=slot)
+      opre, ores = orc.prefill(toks, tl, slot=slot, want_logits=True)
+    else:
+      maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
+      done = 0
+      pre = opre = None
+      for n in chunks[slot]:
+        chunk = np.zeros((cfg.max_prefill_predict_length,), np.int32)
+        chunk[:n] = toks[done:done + n]
+        ep = None if done == 0 else maxengine.ExistingPrefix(cache=pre["cache"], common_prefix_tokens=toks[:done])
+        pre, res = eng.prefill(params=params, padded_tokens=chunk, true_length=n, slot=slot, existing_prefix=ep)
+        opre, ores = orc.prefill(chunk, n, slot=slot, existing_prefix_tokens=None if done == 0 else toks[:done], want_logits=True)
+        done += n
+    assert np.array_equal(res.data.cpu().numpy(), ores), (slot, res.data.cpu().numpy(), ores)
+    assert np.array_equal(pre["logits"].cpu().numpy().reshape(-1).view(np.uint32), opre["logits"].reshape(-1).view(np.uint32))
+    assert int(pre["next_pos"][0, 0]) == int(opre["next_pos"][0, 0])
+    prefixes.append(pre)
+    oprefixes.append(opre)
+  assert_pages_equal(eng, orc)
+  # K/V parity after prefill, every layer
+  for slot, (toks, tl) in enumerate(prompts):
+    n = int(prefixes[slot]["next_pos"][0, 0])
+    for layer in range(cfg.num_decoder_layers):
+      kg, vg = eng.gather_kv(layer, slot, n)
+      ko, vo = orc.model.gather_kv(layer, orc.page_state.page_map[slot], n)
+      assert np.array_equal(H.bits(kg), ko), (slot, layer)
+      assert np.array_equal(H.bits(vg), vo), (slot, layer)
+  ds = eng.init_decode_state(materialize_logits=check_logits)
+  ods = orc.init_decode_state()
+  for slot in range(len(prompts)):
+    ds = eng.insert(prefixes[slot], ds, slot)
+    ods = orc.insert(oprefixes[slot], ods, slot)
+  out = []
+  for i in range(steps):
+    ds, res = eng.generate(params, ds)
+    ods, ores = orc.generate(ods, want_logits=check_logits)
+    got = res.data.cpu().numpy()
+    act = orc.page_state.has_active_page
+    assert np.array_equal(got[act], ores[act]), (i, got, ores)
+    if check_logits:
+      gl = ds["logits"].cpu().numpy().reshape(B, -1)
+      assert np.array_equal(gl[act].view(np.uint32), ods["logits"][act].view(np.uint32)), i
+    out.append(got[:, 0].copy())
+  assert_pages_equal(eng, orc)
+  assert np.array_equal(ds["next_pos"].cpu().numpy(), ods["next_pos"])
+  assert np.array_equal(ds["generated_tokens"].cpu().numpy(), ods["generated_tokens"])
+  for slot, _ in enumerate(prompts):
+    n = int(ods["next_pos"][slot, 0])
+    kg, vg = eng.gather_kv(cfg.num_decoder_layers - 1, slot, n)
+    ko, vo = orc.model.gather_kv(cfg.num_decoder_layers - 1, orc.page_state.page_map[slot], n)
+    assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo)
+  del eng
+  torch.cuda.synchronize()
+  return np.stack(out, 0)
+
+
+def test_tiny_single_slot():
+  cfg = H.make_config()
+  w = H.synth.synth_weights(cfg, 0)
+  toks, tl = H.synth.synth_prompt(cfg.vocab_size, cfg.max_prefill_predict_length, 1234)
+  run_pair(cfg, w, [(toks, tl)], steps=40)
+
+
+@pytest.mark.parametrize("B,nprompts", [(2, 2), (4, 3), (8, 8)])
+def test_tiny_batched_ragged(B, nprompts):
+  """Several slots with different prompt lengths (ragged), fewer prompts than slots (inactive slots)."""
+  cfg = H.make_config(per_device_batch_size=float(B), pagedattn_num_pages=160)
+  w = H.synth.synth_weights(cfg, 1)
+  prompts = []
+  for s in range(nprompts):
+    toks, _ = H.synth.synth_prompt(cfg.vocab_size, cfg.max_prefill_predict_length, 100 + s)
+    prompts.append((toks, [32, 1, 9, 17, 8, 31, 16, 24][s]))
+  run_pair(cfg, w, prompts, steps=40)
+
+
+def test_tiny_graph_equals_eager():
+  cfg_g = H.make_config(per_device_batch_size=2.0, ixt_use_hip_graph=True)
+  cfg_e = H.make_config(per_device_batch_size=2.0, ixt_use_hip_graph=False)
+  w = H.synth.synth_weights(cfg_g, 2)
+  prompts = [H.synth.synth_prompt(cfg_g.vocab_size, 32, 7), H.synth.synth_prompt(cfg_g.vocab_size, 32, 8)]
+  a = run_pair(cfg_g, w, prompts, steps=24)
+  b = run_pair(cfg_e, w, prompts, steps=24)
+  assert np.array_equal(a, b)
+
+
+def test_tiny_chunked_prefill():
+  """Chunked == unchunked exactly (tests/maxengine_test.py:166-300 property), over pages."""
+  cfg = H.make_config(use_chunked_prefill=True, prefill_chunk_size=16, max_prefill_predict_length=32, max_target_length=160,
+                      pagedattn_num_pages=64)
+  w = H.synth.synth_weights(cfg, 3)
+  rng = np.random.default_rng(0)
+  toks = rng.integers(1, cfg.vocab_size, size=75).astype(np.int32)
+  import torch
+  eng, params = H.make_engine(cfg, w)
+  a = run_pair(cfg, w, [(toks, 75)], steps=20, chunks=[[32, 32, 11]])
+  b = run_pair(cfg, w, [(toks, 75)], steps=20, chunks=[[7, 4, 32, 32]])
+  assert np.array_equal(a, b)
+  del eng
+
+
+def test_head_dim_128_mha_page32():
+  """C2's attention geometry (head_dim 128, MHA, 32-token pages) on a small body."""
+  cfg = H.make_config(base_emb_dim=256, base_num_query_heads=2, base_num_kv_heads=2, head_dim=128, base_mlp_dim=384,
+                      base_num_decoder_layers=2, vocab_size=2048, model_name="default", per_device_batch_size=2.0,
+                      max_prefill_predict_length=64, max_target_length=320, pagedattn_tokens_per_page=32, pagedattn_num_pages=24)
+  w = H.synth.synth_weights(cfg, 4)
+  p0 = H.synth.synth_prompt(cfg.vocab_size, 64, 1)
+  p1 = H.synth.synth_prompt(cfg.vocab_size, 64, 2)
+  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False)
+
+
+def test_release_and_reuse_slot():
+  cfg = H.make_config(per_device_batch_size=2.0)
+  w = H.synth.synth_weights(cfg, 5)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  for rep in range(3):
+    for slot in range(2):
+      toks, tl = H.synth.synth_prompt(cfg.vocab_size, 32, 10 * rep + slot)
+      pre, res = eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=slot)
+      opre, ores = orc.prefill(toks, tl, slot=slot)
+      assert np.array_equal(res.data.cpu().numpy(), ores)
+      if rep == 0 and slot == 0:
+        ds, ods = eng.init_decode_state(), orc.init_decode_state()
+      ds = eng.insert(pre, ds, slot)
+      ods = orc.insert(opre, ods, slot)
+    for _ in range(10):
+      ds, res = eng.generate(params, ds)
+      ods, ores = orc.generate(ods)
+      assert np.array_equal(res.data.cpu().numpy(), ores)
+    assert_pages_equal(eng, orc)
+    eng.release_pages(rep % 2)
+    orc.release_pages(rep % 2)
+    assert_pages_equal(eng, orc)
+
+
+def test_errors_match_reference_conventions():
+  cfg = H.make_config()
+  w = H.synth.synth_weights(cfg, 0)
+  eng, params = H.make_engine(cfg, w)
+  toks, tl = H.synth.synth_prompt(cfg.vocab_size, 32, 0)
+  maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
+  with pytest.raises(ValueError):  # maxengine.py:435-436
+    eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=0, existing_prefix=maxengine.ExistingPrefix(None, toks[:4]))
+  with pytest.raises(ValueError):  # page_manager.py:529-530
+    eng.page_manager.update_prefill_pages(None, 5, 4)
+  with pytest.raises(ValueError):  # page_manager.py:531-532
+    eng.page_manager.update_prefill_pages(None, 0, cfg.max_target_length + 1)
+  with pytest.raises(ValueError):
+    eng.page_manager.release_pages(None, -1)
+  with pytest.raises(NotImplementedError):
+    _ = eng.colocated_cpus
+  eng2 = maxengine.MaxEngine(cfg)
+  with pytest.raises(Exception):  # weights never loaded -> loud failure, no fallback
+    eng2.prefill(params=None, padded_tokens=toks, true_length=tl, slot=0)
