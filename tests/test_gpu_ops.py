@@ -55,7 +55,8 @@ def test_rmsnorm(ctx, E):
   for r in range(R):
     O.lib().orc_rmsnorm(O._p(x[r], O._u16p), O._p(sc, O._u16p), O._p(ref[r], O._u16p), E, ctypes.c_float(ctx["cfg"].normalization_layer_epsilon))
   out = torch.empty((R, E), dtype=torch.bfloat16, device="cuda")
-  H.lib.check(eng.lib.ixt_op_rmsnorm(eng._ctx, _vp(H.dev_bf16(x)), _vp(H.dev_bf16(sc)), _vp(out), R, E, _st(torch)))
+  xd, sd = H.dev_bf16(x), H.dev_bf16(sc)  # keep alive across the call
+  H.lib.check(eng.lib.ixt_op_rmsnorm(eng._ctx, _vp(xd), _vp(sd), _vp(out), R, E, _st(torch)))
   assert np.array_equal(H.bits(out), ref)
 
 
@@ -95,7 +96,8 @@ def test_swiglu(ctx):
   ref = np.zeros((n,), np.uint16)
   O.lib().orc_swiglu(O._p(a, O._u16p), O._p(b, O._u16p), O._p(ref, O._u16p), n)
   out = torch.empty((n,), dtype=torch.bfloat16, device="cuda")
-  H.lib.check(eng.lib.ixt_op_swiglu(eng._ctx, _vp(H.dev_bf16(a)), _vp(H.dev_bf16(b)), _vp(out), n, _st(torch)))
+  ad, bd = H.dev_bf16(a), H.dev_bf16(b)
+  H.lib.check(eng.lib.ixt_op_swiglu(eng._ctx, _vp(ad), _vp(bd), _vp(out), n, _st(torch)))
   assert np.array_equal(H.bits(out), ref)
 
 
@@ -176,7 +178,8 @@ def test_unembed_argmax_ties(ctx):
   lg = O.bf16_to_f32(O.f32_to_bf16(lg)).reshape(R, V)
   logits = torch.empty((R, V), dtype=torch.float32, device="cuda")
   amax = torch.empty((R,), dtype=torch.int32, device="cuda")
-  H.lib.check(eng.lib.ixt_op_unembed_argmax(eng._ctx, _vp(H.dev_bf16(y)), R, _vp(logits), _vp(amax), _st(torch)))
+  yd = H.dev_bf16(y)
+  H.lib.check(eng.lib.ixt_op_unembed_argmax(eng._ctx, _vp(yd), R, _vp(logits), _vp(amax), _st(torch)))
   got = logits.cpu().numpy()
   assert np.array_equal(got.view(np.uint32), lg.view(np.uint32))
   assert np.array_equal(amax.cpu().numpy(), np.argmax(lg, axis=-1).astype(np.int32))
