@@ -7,6 +7,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <map>
@@ -59,7 +60,9 @@ struct ixt_ctx {
   PageStateDev ps{};
   // workspaces
   bf16_t *h_a = nullptr, *h_b = nullptr, *xn = nullptr, *qbuf = nullptr, *ao = nullptr, *hact = nullptr;
-  float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *logits = nullptr;
+  float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *amax_val = nullptr;
+  int32_t* amax_idx = nullptr;
+  size_t amax_cap = 0;
   size_t part_floats = 0;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_tok = nullptr, *new_tok = nullptr;
   AttnGeom geom{};
@@ -199,7 +202,9 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   }
   A(dmalloc(x, &x->scores, (size_t)R * x->Q * x->Tmax));
   A(dmalloc(x, &x->pvpart, (size_t)R * x->Q * x->nsb_max * x->D));
-  A(dmalloc(x, &x->logits, (size_t)(x->B > 1 ? x->B : 1) * V));
+  x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 127) / 128);
+  A(dmalloc(x, &x->amax_val, x->amax_cap));
+  A(dmalloc(x, &x->amax_idx, x->amax_cap));
   A(dmalloc(x, &x->row_slot, (size_t)R));
   A(dmalloc(x, &x->row_pos, (size_t)R));
   A(dmalloc(x, &x->row_active, (size_t)R));
@@ -374,46 +379,85 @@ static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
   if (idx >= 0) (void)hipEventRecord(c->tpairs[idx].b, st);
 }
 
-struct DotResult { int slices; size_t slice_stride; };
+struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
-template <int RB>
-static void launch_dot_rb(const DotArgs& a, dim3 grid, bool split, bool nt, hipStream_t st) {
-  if (split) {
-    if (nt) hipLaunchKernelGGL((k_dot<RB, true, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_dot<RB, true, false>), grid, dim3(512), 0, st, a);
+template <int RB, int LW>
+static void launch_dot_v(const DotArgs& a, dim3 grid, bool split, bool nt, bool epi, hipStream_t st) {
+#define DOT_GO(S_, N_, E_) hipLaunchKernelGGL((k_dot<RB, LW, S_, N_, E_>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx)
+  if (epi) {
+    if (nt) DOT_GO(false, true, 1); else DOT_GO(false, false, 1);
+  } else if (split) {
+    if (nt) DOT_GO(true, true, 0); else DOT_GO(true, false, 0);
   } else {
-    if (nt) hipLaunchKernelGGL((k_dot<RB, false, true>), grid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((k_dot<RB, false, false>), grid, dim3(512), 0, st, a);
+    if (nt) DOT_GO(false, true, 0); else DOT_GO(false, false, 0);
   }
+#undef DOT_GO
+}
+template <int RB>
+static void launch_dot_rb(const DotArgs& a, dim3 grid, int lw, bool split, bool nt, bool epi, hipStream_t st) {
+  if (lw == 8) launch_dot_v<RB, 8>(a, grid, split, nt, epi, st);
+  else if (lw == 4) launch_dot_v<RB, 4>(a, grid, split, nt, epi, st);
+  else launch_dot_v<RB, 2>(a, grid, split, nt, epi, st);
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
 }
 
 // out: f32 [slices][R][N]; force_full: one slice (level-2 sum inside the block)
+// epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store logits; (max,idx) pairs -> c->amax_*; *res->ntiles set)
 static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
-                      bool force_full, hipStream_t st, DotResult* res) {
+                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false) {
   if (K % IXT_GL || N % 8) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 128 or N %% 8");
   const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
   const int rowblocks = (R + rb - 1) / rb;
-  const int ntiles = (N + 511) / 512;
   const int G = K / IXT_GL;
-  bool split = !force_full && (ntiles * rowblocks < 224) && G > 1;
+  const int tiles8 = (N + 511) / 512;
+  bool split = !force_full && !epi_argmax && (tiles8 * rowblocks < 224) && G > 1;
   if (split && (size_t)G * R * N > out_floats) split = false;
-  if (!split && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+  if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+  if (out == nullptr && !epi_argmax) return set_err(IXT_ERR_INVALID, "dot: null output");
+  // columns per lane: widest loads that still give the chip >= ~1.5 blocks per CU
+  static const int lw_env = env_int("IXT_DOT_LW", 0);
+  static const int target = env_int("IXT_DOT_TARGET_BLOCKS", 384);
+  int lw = rb == 8 ? 4 : 8;  // 8 rows x 8 columns of accumulators + 16 x 16-B loads do not fit 128 VGPRs (4 waves/SIMD)
+  if (lw_env == 8 || lw_env == 4 || lw_env == 2) lw = lw_env;
+  else {
+    const long per_tile = (long)rowblocks * (split ? G : 1);
+    while (lw > 2 && (long)((N + 64 * lw - 1) / (64 * lw)) * per_tile < target) lw >>= 1;
+  }
+  const int ntiles = (N + 64 * lw - 1) / (64 * lw);
   DotArgs a;
   a.x = x; a.ldx = ldx; a.w = w; a.K = K; a.N = N; a.R = R; a.out = out; a.groups_per_block = 1;
+  if (epi_argmax) {
+    if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+    a.amax_val = c->amax_val; a.amax_idx = c->amax_idx;
+  }
   dim3 grid(ntiles, split ? G : 1, rowblocks);
   const bool nt = rowblocks == 1;
   const double bytes = (double)K * N * 2.0 + (double)R * K * 2.0 + (double)(split ? G : 1) * R * N * 4.0;
   const int ti = timing_begin(c, st, bytes);
   switch (rb) {
-    case 1: launch_dot_rb<1>(a, grid, split, nt, st); break;
-    case 2: launch_dot_rb<2>(a, grid, split, nt, st); break;
-    case 4: launch_dot_rb<4>(a, grid, split, nt, st); break;
-    default: launch_dot_rb<8>(a, grid, split, nt, st); break;
+    case 1: launch_dot_rb<1>(a, grid, lw, split, nt, epi_argmax, st); break;
+    case 2: launch_dot_rb<2>(a, grid, lw, split, nt, epi_argmax, st); break;
+    case 4: launch_dot_rb<4>(a, grid, lw, split, nt, epi_argmax, st); break;
+    default: launch_dot_rb<8>(a, grid, lw, split, nt, epi_argmax, st); break;
   }
   timing_end(c, st, ti);
   LAUNCHCHK();
   res->slices = split ? G : 1;
   res->slice_stride = (size_t)R * N;
+  res->ntiles = ntiles;
+  return IXT_OK;
+}
+
+// logits (optional store) + greedy argmax for R rows of normed hidden states
+static int launch_unembed(ixt_ctx* c, const bf16_t* y, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
+  DotResult dr;
+  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true));
+  hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, dr.ntiles, argmax_out);
+  LAUNCHCHK();
   return IXT_OK;
 }
 
@@ -436,7 +480,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
   pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
   pa.pvpart = c->pvpart; pa.g = g;
-  const size_t lds = sizeof(float) * ((size_t)g.mpg + 4 * IXT_SB * g.P + 8);
+  const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
   hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, out, g);
 }
@@ -460,6 +504,14 @@ static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, co
   else hipLaunchKernelGGL((k_rownorm<2>), dim3(R), dim3(256), lds, st, a);
   LAUNCHCHK();
   return IXT_OK;
+}
+
+// h_out = bf16(h_in + bf16(sum slices)); xn = rmsnorm(h_out) * scale  (two launches: wide slice sum, then one block per row)
+static int launch_sumres_norm(ixt_ctx* c, int R, const DotResult* part, const bf16_t* h_in, bf16_t* h_out, const bf16_t* scale, bf16_t* xn_out,
+                              hipStream_t st) {
+  hipLaunchKernelGGL(k_sumres, dim3((c->E + 255) / 256, R), dim3(128), 0, st, c->part, part->slices, part->slice_stride, h_in, h_out, c->E);
+  LAUNCHCHK();
+  return launch_rownorm(c, 2, R, nullptr, nullptr, h_out, nullptr, scale, xn_out, st);
 }
 
 // The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
@@ -487,19 +539,17 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     }
     TRY(launch_attention(c, l, R, len_hint, c->qbuf, c->ao, st));
     TRY(launch_dot(c, c->ao, c->QN, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
-    TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
+    TRY(launch_sumres_norm(c, R, &dr, hcur, hnext, w.ln2, c->xn, st));
     TRY(launch_dot(c, c->xn, E, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
     hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();
     TRY(launch_dot(c, c->hact, F, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
     const bf16_t* next_scale = (l + 1 < c->L) ? c->layers[l + 1].ln1 : c->final_norm;
-    TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st));
+    TRY(launch_sumres_norm(c, R, &dr, hnext, hcur, next_scale, c->xn, st));
   }
   if (nl > 0) {
     if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
-    TRY(launch_dot(c, c->xn + (size_t)lrow0 * E, E, c->logits_w, E, c->V, nl, c->logits, (size_t)nl * c->V, true, st, &dr));
-    hipLaunchKernelGGL(k_round_argmax, dim3(nl), dim3(1024), 0, st, c->logits, c->V, argmax_out, logits_out);
-    LAUNCHCHK();
+    TRY(launch_unembed(c, c->xn + (size_t)lrow0 * E, nl, logits_out, argmax_out, st));
   }
   return IXT_OK;
 }
@@ -648,11 +698,7 @@ extern "C" int ixt_op_unembed_argmax(ixt_ctx* c, const uint16_t* y, int R, float
   if (!c || !y || !argmax || R <= 0 || R > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "bad argument");
   if (!(c->loaded[c->L] & 4)) return set_err(IXT_ERR_NOT_LOADED, "logits_dense/kernel not loaded");
   hipStream_t st = (hipStream_t)stream;
-  DotResult dr;
-  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, c->logits, (size_t)R * c->V, true, st, &dr));
-  hipLaunchKernelGGL(k_round_argmax, dim3(R), dim3(1024), 0, st, c->logits, c->V, argmax, logits);
-  LAUNCHCHK();
-  return IXT_OK;
+  return launch_unembed(c, y, R, logits, argmax, st);
 }
 
 extern "C" int ixt_kv_gather(ixt_ctx* c, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream) {

@@ -25,107 +25,234 @@ struct DotArgs {
   int K, N, R;
   float* out;        // [slices][R][N]
   int groups_per_block;  // SPLIT: groups handled by one block (blockIdx.y picks the range)
+  float* amax_val = nullptr;     // EPI 1: [R][ntiles]
+  int32_t* amax_idx = nullptr;   // EPI 1: [R][ntiles]
 };
 
-template <int RB, bool SPLIT, bool NT>
-__global__ __launch_bounds__(512) void k_dot(DotArgs a) {
-  constexpr int RH = RB < 4 ? RB : 4;  // rows exchanged through LDS per pass
-  __shared__ float xs[IXT_GL * RB];
-  __shared__ float red[8 * RH * 512];
+template <int LW> struct WVec;
+template <> struct WVec<8> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
+template <> struct WVec<4> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
+template <> struct WVec<2> { typedef uint32_t type; };
+
+template <int LW>
+__device__ __forceinline__ void unpack_w(const typename WVec<LW>::type& v, float* wf) {
+  if constexpr (LW == 8) {
+    wf[0] = bflo(v.x); wf[1] = bfhi(v.x); wf[2] = bflo(v.y); wf[3] = bfhi(v.y);
+    wf[4] = bflo(v.z); wf[5] = bfhi(v.z); wf[6] = bflo(v.w); wf[7] = bfhi(v.w);
+  } else if constexpr (LW == 4) {
+    wf[0] = bflo(v.x); wf[1] = bfhi(v.x); wf[2] = bflo(v.y); wf[3] = bfhi(v.y);
+  } else {
+    wf[0] = bflo(v); wf[1] = bfhi(v);
+  }
+}
+
+// LW = columns per lane (8: 16-B loads, tile 512 columns; 4: 8-B loads, tile 256; 2: 4-B loads, tile 128) -- a pure
+// parallelisation choice for matrices with few column tiles; the numerics do not depend on it.
+// x is wave-uniform per (row, k): it is read with scalar loads (8 dwords = this wave's 16 k of one row) and fed to
+// v_fma as an SGPR operand, so it costs no VGPRs and no LDS.
+// EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded
+// to bf16, optionally stored as f32 logits, and each block emits its (max, first index) pair per row for k_argmax_final.
+template <int RB, int LW, bool SPLIT, bool NT, int EPI>
+__global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, int K, int N, int R,
+                                                float* __restrict__ out, int groups_per_block, float* __restrict__ amax_val,
+                                                int32_t* __restrict__ amax_idx) {
+  typedef typename WVec<LW>::type wvec_t;
+  constexpr int RH = RB < 4 ? RB : 4;  // rows per accumulate/exchange pass
+  constexpr int TW = 64 * LW;          // tile width
+  constexpr int NP = 512 / TW;         // threads per column in the exchange
+  __shared__ __attribute__((aligned(16))) float red[8 * RH * TW];
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
-  const int n0 = blockIdx.x * 512;
-  const int nl = n0 + lane * 8;
-  const bool col_ok = nl < a.N;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int n0 = blockIdx.x * TW;
+  const int nl = n0 + lane * LW;
+  const bool col_ok = nl < N;
   const int r0 = blockIdx.z * RB;
-  const int G = a.K / IXT_GL;
+  const int G = K / IXT_GL;
   int g_begin = 0, g_end = G;
   if (SPLIT) {
-    g_begin = blockIdx.y * a.groups_per_block;
-    g_end = min(G, g_begin + a.groups_per_block);
+    g_begin = blockIdx.y * groups_per_block;
+    g_end = min(G, g_begin + groups_per_block);
   }
+  const int ocol = tid % TW, opart = tid / TW;
   float tot[RB];
 #pragma unroll
   for (int r = 0; r < RB; ++r) tot[r] = 0.0f;
 
   for (int g = g_begin; g < g_end; ++g) {
-    // ---- stage x[r0..r0+RB)[g*128 .. +128) as f32, layout xs[k][RB]
-    for (int i = tid; i < IXT_GL * RB; i += 512) {
-      int r = i % RB, k = i / RB;
-      float v = 0.0f;
-      if (r0 + r < a.R) v = bf2f(a.x[(size_t)(r0 + r) * a.ldx + g * IXT_GL + k]);
-      xs[i] = v;
-    }
-    // ---- this wave's 16 weight rows
-    u32x4 wv[IXT_CL];
     const int kbase = g * IXT_GL + wave * IXT_CL;
+    wvec_t wv[IXT_CL];
     if (col_ok) {
-      const bf16_t* wp = a.w + (size_t)kbase * a.N + nl;
+      const bf16_t* wp = w + (size_t)kbase * N + nl;
 #pragma unroll
       for (int kk = 0; kk < IXT_CL; ++kk) {
-        const u32x4* p = reinterpret_cast<const u32x4*>(wp + (size_t)kk * a.N);
-        if (NT) {
-          wv[kk] = __builtin_nontemporal_load(p);
-        } else {
-          wv[kk] = *p;
-        }
+        const wvec_t* p = reinterpret_cast<const wvec_t*>(wp + (size_t)kk * N);
+        if (NT) wv[kk] = __builtin_nontemporal_load(p);
+        else wv[kk] = *p;
       }
     } else {
 #pragma unroll
-      for (int kk = 0; kk < IXT_CL; ++kk) wv[kk] = u32x4{0, 0, 0, 0};
+      for (int kk = 0; kk < IXT_CL; ++kk) wv[kk] = wvec_t(0);
     }
-    __syncthreads();
-    float acc[RB][8];
-#pragma unroll
-    for (int r = 0; r < RB; ++r)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[r][j] = 0.0f;
-#pragma unroll
-    for (int kk = 0; kk < IXT_CL; ++kk) {
-      float wf[8];
-      wf[0] = bflo(wv[kk].x); wf[1] = bfhi(wv[kk].x);
-      wf[2] = bflo(wv[kk].y); wf[3] = bfhi(wv[kk].y);
-      wf[4] = bflo(wv[kk].z); wf[5] = bfhi(wv[kk].z);
-      wf[6] = bflo(wv[kk].w); wf[7] = bfhi(wv[kk].w);
-      const float* xk = xs + (wave * IXT_CL + kk) * RB;
-#pragma unroll
-      for (int r = 0; r < RB; ++r) {
-        float xv = xk[r];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
-      }
-    }
-    // ---- add the 8 chains of the group in chain order (thread tid owns column n0+tid)
 #pragma unroll
     for (int hh = 0; hh < RB / RH; ++hh) {
-      if (hh > 0) __syncthreads();
+      // this wave's 16 x values of each row of the pass: 8 scalar dwords per row (rows past R re-read row R-1; never stored)
+      uint32_t xw[RH][IXT_CL / 2];
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
-        float* dst = red + ((wave * RH + r) * 512) + lane * 8;
+        const int row = min(r0 + hh * RH + r, R - 1);
+        const uint32_t* xr = reinterpret_cast<const uint32_t*>(x + (size_t)row * ldx + kbase);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) dst[j] = acc[hh * RH + r][j];
+        for (int i = 0; i < IXT_CL / 2; ++i) xw[r][i] = xr[i];
+      }
+      float acc[RH][LW];
+#pragma unroll
+      for (int r = 0; r < RH; ++r)
+#pragma unroll
+        for (int j = 0; j < LW; ++j) acc[r][j] = 0.0f;
+#pragma unroll
+      for (int kk = 0; kk < IXT_CL; ++kk) {
+        float wf[LW];
+        unpack_w<LW>(wv[kk], wf);
+#pragma unroll
+        for (int r = 0; r < RH; ++r) {
+          const float xv = (kk & 1) ? bfhi(xw[r][kk >> 1]) : bflo(xw[r][kk >> 1]);
+#pragma unroll
+          for (int j = 0; j < LW; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
+        }
+      }
+      if (hh + 1 < RB / RH) {
+        // make the weight registers opaque so the next pass re-unpacks them instead of keeping 128 unpacked floats live
+#pragma unroll
+        for (int kk = 0; kk < IXT_CL; ++kk) asm volatile("" : "+v"(wv[kk]));
+      }
+      // ---- add the 8 chains of the group in chain order
+      if (hh > 0 || g > g_begin) __syncthreads();
+#pragma unroll
+      for (int r = 0; r < RH; ++r) {
+        float* dst = red + ((wave * RH + r) * TW) + lane * LW;
+#pragma unroll
+        for (int j = 0; j < LW; ++j) dst[j] = acc[r][j];
       }
       __syncthreads();
 #pragma unroll
       for (int r = 0; r < RH; ++r) {
-        float s = 0.0f;
+        if (RH >= NP ? (r % NP == opart) : (opart == r)) {
+          float s = 0.0f;
 #pragma unroll
-        for (int c = 0; c < IXT_NC; ++c) s = s + red[(c * RH + r) * 512 + tid];
-        if (SPLIT) {
-          if (r0 + hh * RH + r < a.R && n0 + tid < a.N)
-            a.out[((size_t)g * a.R + r0 + hh * RH + r) * a.N + n0 + tid] = s;
-        } else {
-          tot[hh * RH + r] = tot[hh * RH + r] + s;
+          for (int c = 0; c < IXT_NC; ++c) s = s + red[(c * RH + r) * TW + ocol];
+          const int row = r0 + hh * RH + r;
+          if (SPLIT) {
+            if (row < R && n0 + ocol < N) out[((size_t)g * R + row) * N + n0 + ocol] = s;
+          } else {
+            tot[hh * RH + r] = tot[hh * RH + r] + s;
+          }
         }
       }
     }
+  }
+  if (!SPLIT && EPI == 0) {
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool mine = (RH >= NP) ? ((r % RH) % NP == opart) : (opart == (r % RH));
+      if (mine && r0 + r < R && n0 + ocol < N) out[(size_t)(r0 + r) * N + n0 + ocol] = tot[r];
+    }
+  }
+  if (!SPLIT && EPI == 1) {
+    // tile of rounded logits in LDS: red[r][TW] (RB*TW <= 8*RH*TW floats)
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RB; ++r) {
+      const bool mine = (RH >= NP) ? ((r % RH) % NP == opart) : (opart == (r % RH));
+      if (mine) red[r * TW + ocol] = (n0 + ocol < N) ? rbf(tot[r]) : -INFINITY;
+    }
+    __syncthreads();
+    if (out != nullptr) {
+      for (int i = tid; i < RB * TW; i += 512) {
+        const int r = i / TW, c = i % TW;
+        if (r0 + r < R && n0 + c < N) out[(size_t)(r0 + r) * N + n0 + c] = red[i];
+      }
+    }
+    if (wave < RB && r0 + wave < R) {
+      float best = -INFINITY;
+      int bidx = 0x7fffffff;
+#pragma unroll
+      for (int c = lane; c < TW; c += 64) {
+        const float v = red[wave * TW + c];
+        if (v > best) { best = v; bidx = n0 + c; }   // ascending c: first index wins ties
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      }
+      if (lane == 0) {
+        amax_val[(size_t)(r0 + wave) * gridDim.x + blockIdx.x] = best;
+        amax_idx[(size_t)(r0 + wave) * gridDim.x + blockIdx.x] = bidx;
+      }
+    }
+  }
+}
+
+// final (max, first index) over the per-tile pairs.  grid = R, block 256.
+__global__ __launch_bounds__(256) void k_argmax_final(const float* amax_val, const int32_t* amax_idx, int ntiles, int32_t* out_idx) {
+  __shared__ float bv[256];
+  __shared__ int bi[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  float best = -INFINITY;
+  int bidx = 0x7fffffff;
+  for (int t = tid; t < ntiles; t += 256) {
+    const float v = amax_val[(size_t)r * ntiles + t];
+    const int i2 = amax_idx[(size_t)r * ntiles + t];
+    if (v > best || (v == best && i2 < bidx)) { best = v; bidx = i2; }
+  }
+  bv[tid] = best; bi[tid] = bidx;
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if (tid < s2) {
+      const float v = bv[tid + s2]; const int i2 = bi[tid + s2];
+      if (v > bv[tid] || (v == bv[tid] && i2 < bi[tid])) { bv[tid] = v; bi[tid] = i2; }
+    }
     __syncthreads();
   }
-  if (!SPLIT) {
+  if (tid == 0) out_idx[r] = bi[0] == 0x7fffffff ? 0 : bi[0];
+}
+
+// Sum of partial slices in slice order, with the loads of up to U slices issued together (the adds stay
+// sequential; padding with +0.0f is exact because a running sum that started at +0.0f is never -0.0f).
+template <int U>
+__device__ __forceinline__ float sum_slices(const float* p, size_t stride, int slices) {
+  float t = 0.0f;
+  for (int s0 = 0; s0 < slices; s0 += U) {
+    float v[U];
 #pragma unroll
-    for (int r = 0; r < RB; ++r)
-      if (r0 + r < a.R && n0 + tid < a.N) a.out[(size_t)(r0 + r) * a.N + n0 + tid] = tot[r];
+    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? p[(size_t)(s0 + u) * stride] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) t = t + v[u];
   }
+  return t;
+}
+template <int U>
+__device__ __forceinline__ float2 sum_slices2(const float* p, size_t stride, int slices) {
+  float2 t = make_float2(0.0f, 0.0f);
+  for (int s0 = 0; s0 < slices; s0 += U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? *reinterpret_cast<const float2*>(p + (size_t)(s0 + u) * stride) : make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { t.x = t.x + v[u].x; t.y = t.y + v[u].y; }
+  }
+  return t;
+}
+
+// h_out = bf16(h_in + bf16(sum of slices))  (llama2.py:127, :157).  grid = (ceil(E/256), R), block 128, 2 columns per thread.
+__global__ __launch_bounds__(128) void k_sumres(const float* part, int slices, size_t slice_stride, const bf16_t* h_in, bf16_t* h_out, int E) {
+  const int c = (blockIdx.x * 128 + threadIdx.x) * 2, r = blockIdx.y;
+  if (c >= E) return;
+  const float2 o = sum_slices2<16>(part + (size_t)r * E + c, slice_stride, slices);
+  const uint32_t hv = *reinterpret_cast<const uint32_t*>(h_in + (size_t)r * E + c);
+  const bf16_t a = f2bf(bflo(hv) + rbf(o.x)), b = f2bf(bfhi(hv) + rbf(o.y));
+  *reinterpret_cast<uint32_t*>(h_out + (size_t)r * E + c) = pack2(a, b);
 }
 
 // =====================================================================================================
@@ -224,12 +351,9 @@ __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slic
                                                       bf16_t* out /*[R][F]*/) {
   const int f = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (f >= F) return;
-  float a = 0.0f, b = 0.0f;
-  for (int s = 0; s < slices; ++s) {
-    const float* p = part + (size_t)s * slice_stride + (size_t)r * 2 * F;
-    a = a + p[f];
-    b = b + p[F + f];
-  }
+  const float* p = part + (size_t)r * 2 * F;
+  const float a = sum_slices<16>(p + f, slice_stride, slices);
+  const float b = sum_slices<16>(p + F + f, slice_stride, slices);
   out[(size_t)r * F + f] = ixt_swiglu(rbf(a), rbf(b));
 }
 
@@ -272,14 +396,9 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
   const int half = g.hd / 2;
   if (i >= half) return;
   const int col0 = hh * g.hd;
-  float v1 = 0.0f, v2 = 0.0f;
-  for (int s = 0; s < a.slices; ++s) {
-    const float* p = a.part + (size_t)s * a.slice_stride + (size_t)r * a.ncols + col0;
-    v1 = v1 + p[i];
-    v2 = v2 + p[half + i];
-  }
-  v1 = rbf(v1);
-  v2 = rbf(v2);
+  const float* pq = a.part + (size_t)r * a.ncols + col0;
+  float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
+  float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
   const int pos = a.row_pos[r];
   const bool is_v = hh >= g.nq + g.nkv;
   if (!is_v) {
@@ -414,49 +533,48 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
   const int pages = (kv_len + g.P - 1) / g.P;
   const int nsb = (pages + IXT_SB - 1) / IXT_SB;
   if (chunk * 4 >= nsb) return;
-  const int maxpages = g.mpg;
-  float* psum = sm;                       // [maxpages]
-  float* pbuf = sm + maxpages;            // [4 super-blocks * 4 pages * P]
-  float* wred = pbuf + 4 * IXT_SB * g.P;  // [8]
+  float* ebuf = sm;                       // [mpg * P] scores -> exps -> (own range) normalised P
+  float* psum = sm + (size_t)g.mpg * g.P; // [mpg]
+  float* wred = psum + g.mpg;             // [8]
   const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
   constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
   constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
   const int j0 = chunk * 4 * IXT_SB * g.P;  // first key of this block's range
+  const int j1 = min(kv_len, j0 + 4 * IXT_SB * g.P);
 
   for (int q = 0; q < GQ; ++q) {
     const int h = kvh * GQ + q;
     const float* srow = a.scores + ((size_t)r * g.nq + h) * g.Tmax;
-    // max (order independent)
+    if (q > 0) __syncthreads();
+    // scores -> LDS (coalesced), max (order independent)
     float m = -INFINITY;
-    for (int j = tid; j < kv_len; j += 256) m = fmaxf(m, srow[j]);
+    for (int j = tid; j < kv_len; j += 256) {
+      const float sv = srow[j];
+      ebuf[j] = sv;
+      m = fmaxf(m, sv);
+    }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
-    __syncthreads();  // protects wred / psum / pbuf reuse across q iterations
     if (lane == 0) wred[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    // exp + page sums: thread p owns logical page p
+    for (int j = tid; j < kv_len; j += 256) ebuf[j] = ixt_exp(ebuf[j] - m);
+    __syncthreads();
+    // page sums in key order: thread p owns logical page p
     for (int p = tid; p < pages; p += 256) {
-      float s = 0.0f;
-      const int j1 = min((p + 1) * g.P, kv_len);
-      for (int j = p * g.P; j < j1; ++j) {
-        const float e = ixt_exp(srow[j] - m);
-        s = s + e;
-        const int rel = j - j0;
-        if (rel >= 0 && rel < 4 * IXT_SB * g.P) pbuf[rel] = e;
-      }
-      psum[p] = s;
+      float sacc = 0.0f;
+      const int e1 = min((p + 1) * g.P, kv_len);
+      for (int j = p * g.P; j < e1; ++j) sacc = sacc + ebuf[j];
+      psum[p] = sacc;
     }
     __syncthreads();
     float l = 0.0f;
     for (int p = 0; p < pages; ++p) l = l + psum[p];
-    for (int rel = tid; rel < 4 * IXT_SB * g.P; rel += 256)
-      if (j0 + rel < kv_len) pbuf[rel] = rbf(pbuf[rel] / l);
+    for (int j = j0 + tid; j < j1; j += 256) ebuf[j] = rbf(ebuf[j] / l);
     __syncthreads();
     // PV: a wave covers PPW pages at once = PPW/4 super-blocks
     const int tq = lane / LPP, dc = lane % LPP;
     if (wave * PPW < 4 * IXT_SB) {
-      const int pass = 0;
       const int pg_local = wave * PPW + tq;  // 0..15: page within this block's 16-page range
       const int p = chunk * 4 * IXT_SB + pg_local;
       float acc[8];
@@ -466,13 +584,22 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
         const int page = prow[p];
         const bf16_t* vp = a.vpages + vpage_off(g, page, kvh, 0) + dc * 8;
         const int ntok = min(g.P, kv_len - p * g.P);
-        for (int t = 0; t < ntok; ++t) {
-          const u32x4 vv = *reinterpret_cast<const u32x4*>(vp + (size_t)t * HD);
-          const float pj = pbuf[pg_local * g.P + t];
-          acc[0] = __builtin_fmaf(pj, bflo(vv.x), acc[0]); acc[1] = __builtin_fmaf(pj, bfhi(vv.x), acc[1]);
-          acc[2] = __builtin_fmaf(pj, bflo(vv.y), acc[2]); acc[3] = __builtin_fmaf(pj, bfhi(vv.y), acc[3]);
-          acc[4] = __builtin_fmaf(pj, bflo(vv.z), acc[4]); acc[5] = __builtin_fmaf(pj, bfhi(vv.z), acc[5]);
-          acc[6] = __builtin_fmaf(pj, bflo(vv.w), acc[6]); acc[7] = __builtin_fmaf(pj, bfhi(vv.w), acc[7]);
+        const float* pj = ebuf + (size_t)p * g.P;
+        for (int t0 = 0; t0 < ntok; t0 += 8) {
+          u32x4 vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            vv[u] = (t0 + u < ntok) ? *reinterpret_cast<const u32x4*>(vp + (size_t)(t0 + u) * HD) : u32x4(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (t0 + u < ntok) {
+              const float pv = pj[t0 + u];
+              acc[0] = __builtin_fmaf(pv, bflo(vv[u].x), acc[0]); acc[1] = __builtin_fmaf(pv, bfhi(vv[u].x), acc[1]);
+              acc[2] = __builtin_fmaf(pv, bflo(vv[u].y), acc[2]); acc[3] = __builtin_fmaf(pv, bfhi(vv[u].y), acc[3]);
+              acc[4] = __builtin_fmaf(pv, bflo(vv[u].z), acc[4]); acc[5] = __builtin_fmaf(pv, bfhi(vv[u].z), acc[5]);
+              acc[6] = __builtin_fmaf(pv, bflo(vv[u].w), acc[6]); acc[7] = __builtin_fmaf(pv, bfhi(vv[u].w), acc[7]);
+            }
+          }
         }
       }
       // super-block sum: pages 4s..4s+3 live in lane groups tq = 4s'..4s'+3 of this wave
@@ -487,7 +614,7 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
         for (int j = 0; j < 8; ++j) sbs[j] = sbs[j] + __shfl(acc[j], base_lane + i * LPP, 64);
       }
       if (tq % IXT_SB == 0) {
-        const int sb = chunk * 4 + ((pass * 4 + wave) * PPW) / IXT_SB + sbl;
+        const int sb = chunk * 4 + (wave * PPW) / IXT_SB + sbl;
         if (sb < nsb) {
           float* dst = a.pvpart + (((size_t)r * g.nq + h) * g.nsb_max + sb) * HD + dc * 8;
           *reinterpret_cast<float4*>(dst) = make_float4(sbs[0], sbs[1], sbs[2], sbs[3]);
@@ -508,8 +635,7 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const
   const int n = g.nq * g.hd;
   for (int i = threadIdx.x; i < n; i += 256) {
     const int h = i / g.hd, d = i % g.hd;
-    float t = 0.0f;
-    for (int sb = 0; sb < nsb; ++sb) t = t + pvpart[(((size_t)r * g.nq + h) * g.nsb_max + sb) * g.hd + d];
+    const float t = sum_slices<8>(pvpart + (((size_t)r * g.nq + h) * g.nsb_max) * g.hd + d, (size_t)g.hd, nsb);
     out[(size_t)r * n + i] = f2bf(t);
   }
 }
