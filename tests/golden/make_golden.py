@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (run in the build container, where /root/reference is mounted):
+
+  audio_token_mapping_adjusted.npz   the reference's audio-id <-> embedding-row table (data file
+                                     /root/reference/audio_token_mapping_adjusted.json) in array form
+  tiny_decode.npz / c1_decode.npz / c2_decode.npz
+                                     greedy token ids produced by the CPU ORACLE (oracle/ixt_oracle.c) on seeded synthetic
+                                     weights and prompts.  These pin the oracle against drift and give the GPU tests a
+                                     full-size (C2, 1024-step) target without re-running the oracle on the GPU box.
+
+The floating-point fixtures are oracle outputs, NOT reference outputs (the reference needs JAX, which is not installed:
+parity unpinned).  usage: make_golden.py [mapping] [tiny] [c1] [c2]
+"""
+import hashlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import helpers as H  # noqa: E402
+
+
+def mapping():
+  src = "/root/reference/audio_token_mapping_adjusted.json"
+  raw = open(src, "rb").read()
+  d = json.loads(raw)
+  a2e = np.full((8192,), -1, np.int32)
+  for k, v in d["audio_to_embedding"].items():
+    a2e[int(k)] = int(v)
+  rows = np.array(sorted(int(k) for k in d["embedding_to_audio"]), np.int32)
+  aud = np.array([int(d["embedding_to_audio"][str(r)]) for r in rows], np.int32)
+  np.savez_compressed(os.path.join(HERE, "audio_token_mapping_adjusted.npz"), audio_to_embedding=a2e, embedding_rows=rows, embedding_audio_id=aud,
+                      stats=np.array(json.dumps(d["stats"])), sha256=np.array(hashlib.sha256(raw).hexdigest()))
+  print("mapping:", d["stats"], hashlib.sha256(raw).hexdigest()[:8])
+
+
+def decode_fixture(name, cfg, seed_w, prompts, steps, B):
+  from oracle import oracle as O
+  t0 = time.time()
+  w = H.synth.synth_weights(cfg, seed_w)
+  print(name, "weights", time.time() - t0, flush=True)
+  orc = H.make_oracle(cfg, w)
+  firsts, oprefixes = [], []
+  for s, (toks, tl) in enumerate(prompts):
+    opre, ores = orc.prefill(toks, tl, slot=s)
+    firsts.append(int(ores[0, 0]))
+    oprefixes.append(opre)
+  print(name, "prefill", time.time() - t0, flush=True)
+  ods = orc.init_decode_state()
+  for s in range(len(prompts)):
+    ods = orc.insert(oprefixes[s], ods, s)
+  out = np.zeros((steps + 1, B), np.int32)
+  out[0, :len(prompts)] = firsts
+  for i in range(steps):
+    ods, r = orc.generate(ods)
+    out[i + 1] = r[:, 0]
+    if i % 64 == 0:
+      print(name, "step", i, time.time() - t0, flush=True)
+  np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=out, prompt_tokens=np.stack([p[0] for p in prompts]),
+                      true_lengths=np.array([p[1] for p in prompts], np.int32), weight_seed=np.array(seed_w), steps=np.array(steps))
+  print(name, "done", time.time() - t0, out[:6].tolist(), flush=True)
+
+
+def tiny():
+  cfg = H.make_config(per_device_batch_size=2.0)
+  prompts = [H.synth.synth_prompt(cfg.vocab_size, 32, 1234), H.synth.synth_prompt(cfg.vocab_size, 32, 1235)]
+  decode_fixture("tiny_decode", cfg, 0, prompts, 64, 2)
+
+
+def c1():
+  cfg = H.make_config(model_name="c1-134m", per_device_batch_size=1.0, max_prefill_predict_length=64, max_target_length=128,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=8)
+  prompts = [H.synth.synth_prompt(cfg.vocab_size, 64, 1234)]
+  decode_fixture("c1_decode", cfg, 0, prompts, 64, 1)
+
+
+def c2():
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=1.0, max_prefill_predict_length=256, max_target_length=1280,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=41)
+  prompts = [H.synth.synth_prompt(cfg.vocab_size, 256, 1234)]
+  decode_fixture("c2_decode", cfg, 0, prompts, 1024, 1)
+
+
+if __name__ == "__main__":
+  which = sys.argv[1:] or ["mapping", "tiny", "c1"]
+  for w in which:
+    {"mapping": mapping, "tiny": tiny, "c1": c1, "c2": c2}[w]()

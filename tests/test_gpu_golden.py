@@ -1,0 +1,100 @@
+"""GPU parity against the committed golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py with the
+CPU oracle): full-size C2 (1B, 256-token prefill -> 1024 greedy steps), C1 (134M) and the tiny model, plus
+size-independent properties at full size (batch rows independent, teacher-forced prefill == decode)."""
+import os
+
+import numpy as np
+import pytest
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def run_engine(cfg, w, prompts, steps):
+  eng, params = H.make_engine(cfg, w)
+  pres, firsts = [], []
+  for s, (t, tl) in enumerate(prompts):
+    p, r = eng.prefill(params=params, padded_tokens=t, true_length=tl, slot=s)
+    pres.append(p)
+    firsts.append(r.data)
+  ds = eng.init_decode_state()
+  for s in range(len(prompts)):
+    ds = eng.insert(pres[s], ds, s)
+  res = []
+  for _ in range(steps):
+    ds, r = eng.generate(params, ds)
+    res.append(r.data)
+  B = int(cfg.per_device_batch_size)
+  out = np.zeros((steps + 1, B), np.int32)
+  for s in range(len(prompts)):
+    out[0, s] = int(firsts[s][0, 0])
+  import torch
+  out[1:] = torch.stack(res)[:, :, 0].cpu().numpy()
+  return out, eng, params
+
+
+def test_golden_tiny():
+  g = np.load(os.path.join(H.GOLDEN, "tiny_decode.npz"))
+  cfg = H.make_config(per_device_batch_size=2.0)
+  w = H.synth.synth_weights(cfg, int(g["weight_seed"]))
+  prompts = [(g["prompt_tokens"][i], int(g["true_lengths"][i])) for i in range(2)]
+  out, _, _ = run_engine(cfg, w, prompts, int(g["steps"]))
+  assert np.array_equal(out, g["tokens"])
+
+
+def test_golden_c1():
+  g = np.load(os.path.join(H.GOLDEN, "c1_decode.npz"))
+  cfg = H.make_config(model_name="c1-134m", per_device_batch_size=1.0, max_prefill_predict_length=64, max_target_length=128,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=8)
+  w = H.synth.synth_weights(cfg, int(g["weight_seed"]))
+  out, _, _ = run_engine(cfg, w, [(g["prompt_tokens"][0], int(g["true_lengths"][0]))], int(g["steps"]))
+  assert np.array_equal(out, g["tokens"])
+
+
+@pytest.fixture(scope="module")
+def c2_weights():
+  path = os.path.join(H.GOLDEN, "c2_decode.npz")
+  if not os.path.exists(path):
+    pytest.skip("c2 golden fixture not generated")
+  g = np.load(path)
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=1.0, max_prefill_predict_length=256, max_target_length=1280,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=41)
+  return g, H.synth.synth_weights(cfg, int(g["weight_seed"]))
+
+
+def test_golden_c2_full_decode(c2_weights):
+  """BASELINE.json configs[1] at full size: every one of the 1025 token ids equals the oracle's."""
+  g, w = c2_weights
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=1.0, max_prefill_predict_length=256, max_target_length=1280,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=41)
+  out, _, _ = run_engine(cfg, w, [(g["prompt_tokens"][0], int(g["true_lengths"][0]))], int(g["steps"]))
+  assert np.array_equal(out, g["tokens"]), int(np.argmax(np.any(out != g["tokens"], axis=1)))
+
+
+def test_c2_batch8_properties(c2_weights):
+  """Full-size, batch 8: slot 0 carries the golden utterance and must reproduce it whatever the other slots hold;
+  two slots with the same prompt give the same tokens; teacher-forced chunked prefill of prompt+generated tokens
+  reproduces the decode path's next token (prefill == decode, tests/model_test.py:115-191 property)."""
+  g, w = c2_weights
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=8.0, max_prefill_predict_length=256, max_target_length=1280,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=8 * 40 + 1, use_chunked_prefill=True, prefill_chunk_size=256)
+  p0 = (g["prompt_tokens"][0], int(g["true_lengths"][0]))
+  prompts = [p0] + [H.synth.synth_prompt(cfg.vocab_size, 256, 2000 + s) for s in range(1, 7)] + [p0]
+  steps = 300
+  out, eng, params = run_engine(cfg, w, prompts, steps)
+  assert np.array_equal(out[:, 0], g["tokens"][:steps + 1, 0])
+  assert np.array_equal(out[:, 7], out[:, 0])
+  # teacher forcing through chunked prefill into slot 1 (released first): prompt + first 299 generated tokens
+  maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
+  eng.release_pages(1)
+  seq = np.concatenate([p0[0][:p0[1]], out[:steps, 0]]).astype(np.int32)
+  done, pre = 0, None
+  while done < len(seq):
+    n = min(256, len(seq) - done)
+    chunk = np.zeros((256,), np.int32)
+    chunk[:n] = seq[done:done + n]
+    ep = None if done == 0 else maxengine.ExistingPrefix(cache=pre["cache"], common_prefix_tokens=seq[:done])
+    pre, res = eng.prefill(params=params, padded_tokens=chunk, true_length=n, slot=1, existing_prefix=ep)
+    done += n
+  assert int(res.data[0, 0]) == int(out[steps, 0])
