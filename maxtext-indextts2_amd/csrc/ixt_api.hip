@@ -63,6 +63,8 @@ struct ixt_ctx {
   float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   size_t amax_cap = 0;
+  float* chunk = nullptr;  // [R][E/8] chunk sums of squares of the current residual stream
+  int nblk = 0;
   size_t part_floats = 0;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_tok = nullptr, *new_tok = nullptr;
   AttnGeom geom{};
@@ -205,6 +207,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 127) / 128);
   A(dmalloc(x, &x->amax_val, x->amax_cap));
   A(dmalloc(x, &x->amax_idx, x->amax_cap));
+  x->nblk = (E / 8 + 63) / 64;
+  A(dmalloc(x, &x->chunk, (size_t)R * (E / 8)));
   A(dmalloc(x, &x->row_slot, (size_t)R));
   A(dmalloc(x, &x->row_pos, (size_t)R));
   A(dmalloc(x, &x->row_active, (size_t)R));
@@ -382,22 +386,26 @@ static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
 struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
 template <int RB, int LW>
-static void launch_dot_v(const DotArgs& a, dim3 grid, bool split, bool nt, bool epi, hipStream_t st) {
-#define DOT_GO(S_, N_, E_) hipLaunchKernelGGL((k_dot<RB, LW, S_, N_, E_>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx)
+static void launch_dot_v(const DotArgs& a, const DotX& xa, dim3 grid, bool split, int nt, bool epi, hipStream_t st) {
+#define DOT_GO(S_, X_, E_)                                                                                                             \
+  do {                                                                                                                                 \
+    if (nt) hipLaunchKernelGGL((k_dot<RB, LW, S_, X_, E_, true>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx, xa);  \
+    else hipLaunchKernelGGL((k_dot<RB, LW, S_, X_, E_, false>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx, xa); \
+  } while (0)
   if (epi) {
-    if (nt) DOT_GO(false, true, 1); else DOT_GO(false, false, 1);
+    if (a.xmode == 1) DOT_GO(false, 1, 1); else DOT_GO(false, 0, 1);
   } else if (split) {
-    if (nt) DOT_GO(true, true, 0); else DOT_GO(true, false, 0);
+    if (a.xmode == 1) DOT_GO(true, 1, 0); else if (a.xmode == 2) DOT_GO(true, 2, 0); else DOT_GO(true, 0, 0);
   } else {
-    if (nt) DOT_GO(false, true, 0); else DOT_GO(false, false, 0);
+    if (a.xmode == 1) DOT_GO(false, 1, 0); else if (a.xmode == 2) DOT_GO(false, 2, 0); else DOT_GO(false, 0, 0);
   }
 #undef DOT_GO
 }
 template <int RB>
-static void launch_dot_rb(const DotArgs& a, dim3 grid, int lw, bool split, bool nt, bool epi, hipStream_t st) {
-  if (lw == 8) launch_dot_v<RB, 8>(a, grid, split, nt, epi, st);
-  else if (lw == 4) launch_dot_v<RB, 4>(a, grid, split, nt, epi, st);
-  else launch_dot_v<RB, 2>(a, grid, split, nt, epi, st);
+static void launch_dot_rb(const DotArgs& a, const DotX& xa, dim3 grid, int lw, bool split, int nt, bool epi, hipStream_t st) {
+  if (lw == 8) launch_dot_v<RB, 8>(a, xa, grid, split, nt, epi, st);
+  else if (lw == 4) launch_dot_v<RB, 4>(a, xa, grid, split, nt, epi, st);
+  else launch_dot_v<RB, 2>(a, xa, grid, split, nt, epi, st);
 }
 
 static int env_int(const char* name, int dflt) {
@@ -408,7 +416,7 @@ static int env_int(const char* name, int dflt) {
 // out: f32 [slices][R][N]; force_full: one slice (level-2 sum inside the block)
 // epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store logits; (max,idx) pairs -> c->amax_*; *res->ntiles set)
 static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
-                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false) {
+                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false, int xmode = 0, const DotX* xa = nullptr) {
   if (K % IXT_GL || N % 8) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 128 or N %% 8");
   const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
   const int rowblocks = (R + rb - 1) / rb;
@@ -434,15 +442,18 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int
     if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
     a.amax_val = c->amax_val; a.amax_idx = c->amax_idx;
   }
+  a.xmode = xmode;
+  DotX xz{};
+  if (xa) xz = *xa;
   dim3 grid(ntiles, split ? G : 1, rowblocks);
-  const bool nt = rowblocks == 1;
+  const int nt = rowblocks == 1 ? 1 : 0;
   const double bytes = (double)K * N * 2.0 + (double)R * K * 2.0 + (double)(split ? G : 1) * R * N * 4.0;
   const int ti = timing_begin(c, st, bytes);
   switch (rb) {
-    case 1: launch_dot_rb<1>(a, grid, lw, split, nt, epi_argmax, st); break;
-    case 2: launch_dot_rb<2>(a, grid, lw, split, nt, epi_argmax, st); break;
-    case 4: launch_dot_rb<4>(a, grid, lw, split, nt, epi_argmax, st); break;
-    default: launch_dot_rb<8>(a, grid, lw, split, nt, epi_argmax, st); break;
+    case 1: launch_dot_rb<1>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
+    case 2: launch_dot_rb<2>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
+    case 4: launch_dot_rb<4>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
+    default: launch_dot_rb<8>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
   }
   timing_end(c, st, ti);
   LAUNCHCHK();
@@ -453,9 +464,10 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int
 }
 
 // logits (optional store) + greedy argmax for R rows of normed hidden states
-static int launch_unembed(ixt_ctx* c, const bf16_t* y, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
+static int launch_unembed(ixt_ctx* c, const bf16_t* y, int R, float* logits_out, int32_t* argmax_out, hipStream_t st, int xmode = 0,
+                          const DotX* xa = nullptr) {
   DotResult dr;
-  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true));
+  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true, xmode, xa));
   hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, dr.ntiles, argmax_out);
   LAUNCHCHK();
   return IXT_OK;
@@ -514,20 +526,94 @@ static int launch_sumres_norm(ixt_ctx* c, int R, const DotResult* part, const bf
   return launch_rownorm(c, 2, R, nullptr, nullptr, h_out, nullptr, scale, xn_out, st);
 }
 
+template <int HD, int GQ>
+static void launch_front_pv(ixt_ctx* c, int layer, int R, int len_hint, const DotResult& dr, hipStream_t st) {
+  const AttnGeom& g = c->geom;
+  const int pages_hint = (len_hint + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;
+  int nsplit = (pages_hint + 4 * ppw - 1) / (4 * ppw);
+  if (nsplit < 1) nsplit = 1;
+  FrontArgs fa;
+  fa.part = c->part; fa.slices = dr.slices; fa.slice_stride = dr.slice_stride; fa.ncols = c->NQKV;
+  fa.row_slot = c->row_slot; fa.row_pos = c->row_pos; fa.row_active = c->row_active; fa.page_map = c->ps.page_map;
+  fa.rope_sin = c->rope_sin; fa.rope_cos = c->rope_cos;
+  fa.kpages = c->kpages + (size_t)layer * c->layer_page_elems; fa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  fa.scores = c->scores; fa.g = g;
+  hipLaunchKernelGGL((k_attn_front_decode<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, fa);
+  const int nsb_hint = (pages_hint + IXT_SB - 1) / IXT_SB;
+  int nchunk = (nsb_hint + 3) / 4;
+  if (nchunk < 1) nchunk = 1;
+  PvArgs pa;
+  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
+  pa.pvpart = c->pvpart; pa.g = g;
+  const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
+  hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
+}
+
+template <int HD, int GQ>
+static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStream_t st) {
+  const AttnGeom& g = c->geom;
+  const int pages_hint = (len_hint + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;
+  int nsplit = (pages_hint + 4 * ppw - 1) / (4 * ppw);
+  if (nsplit < 1) nsplit = 1;
+  ScoreArgs sa;
+  sa.qbuf = c->qbuf; sa.kpages = c->kpages + (size_t)layer * c->layer_page_elems;
+  sa.row_slot = c->row_slot; sa.row_pos = c->row_pos; sa.row_active = c->row_active; sa.page_map = c->ps.page_map;
+  sa.scores = c->scores; sa.g = g;
+  hipLaunchKernelGGL((k_attn_scores<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, sa);
+  const int nsb_hint = (pages_hint + IXT_SB - 1) / IXT_SB;
+  int nchunk = (nsb_hint + 3) / 4;
+  if (nchunk < 1) nchunk = 1;
+  PvArgs pa;
+  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
+  pa.pvpart = c->pvpart; pa.g = g;
+  const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
+  hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
+}
+
+// attention up to the per-super-block partials (c->pvpart); decode rows use the fused front kernel
+static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint, const DotResult& qkv, bool decode, hipStream_t st) {
+#define ATT(HD_, GQ_)                                                                             \
+  if (c->D == HD_ && c->GQ == GQ_) {                                                              \
+    if (decode) launch_front_pv<HD_, GQ_>(c, layer, R, len_hint, qkv, st);                        \
+    else launch_scores_pv<HD_, GQ_>(c, layer, R, len_hint, st);                                   \
+    LAUNCHCHK();                                                                                  \
+    return IXT_OK;                                                                                \
+  }
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
+}
+
 // The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
-// Logits are produced for rows [lrow0, lrow0+nl).
+// Logits are produced for rows [lrow0, lrow0+nl).  decode: one new token per row (rows never read each other's new K).
+// Launches per layer: dot_qkv, [front | qkv_finalize + scores], pv, dot_o (x = combined attention partials), sumres_blk,
+// dot_wi (x = RMSNorm on the fly), swiglu, dot_wo, sumres_blk.
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, int32_t* argmax_out,
-                        float* logits_out, hipStream_t st) {
+                        float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
   const int E = c->E, F = c->F;
   DotResult dr;
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
+  DotX xn{};
+  xn.chunk = c->chunk; xn.nchunks = E / 8; xn.nblk = c->nblk; xn.eps = c->cfg.normalization_layer_epsilon;
+  DotX xc{};
+  xc.pvpart = c->pvpart; xc.row_pos = c->row_pos; xc.row_active = c->row_active; xc.nq = c->Q; xc.hd = c->D; xc.P = c->P; xc.nsb_max = c->nsb_max;
+  // layer 0 input: embedding rows, normalised by the row kernel (no block sums exist yet)
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
-    TRY(launch_dot(c, c->xn, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
-    {
+    if (l == 0) {
+      TRY(launch_dot(c, c->xn, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
+    } else {
+      xn.h = hcur; xn.scale = w.ln1;
+      TRY(launch_dot(c, nullptr, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr, false, 1, &xn));
+    }
+    if (!decode) {
       QkvArgs qa;
       qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
       qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
@@ -537,19 +623,22 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
       LAUNCHCHK();
     }
-    TRY(launch_attention(c, l, R, len_hint, c->qbuf, c->ao, st));
-    TRY(launch_dot(c, c->ao, c->QN, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
-    TRY(launch_sumres_norm(c, R, &dr, hcur, hnext, w.ln2, c->xn, st));
-    TRY(launch_dot(c, c->xn, E, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
+    TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));
+    TRY(launch_dot(c, nullptr, c->QN, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr, false, 2, &xc));
+    hipLaunchKernelGGL(k_sumres_chunk, dim3((E + 127) / 128, R), dim3(64), 0, st, c->part, dr.slices, dr.slice_stride, hcur, hnext, c->chunk, E);
+    LAUNCHCHK();
+    xn.h = hnext; xn.scale = w.ln2;
+    TRY(launch_dot(c, nullptr, E, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr, false, 1, &xn));
     hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();
     TRY(launch_dot(c, c->hact, F, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
-    const bf16_t* next_scale = (l + 1 < c->L) ? c->layers[l + 1].ln1 : c->final_norm;
-    TRY(launch_sumres_norm(c, R, &dr, hnext, hcur, next_scale, c->xn, st));
+    hipLaunchKernelGGL(k_sumres_chunk, dim3((E + 127) / 128, R), dim3(64), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, c->chunk, E);
+    LAUNCHCHK();
   }
   if (nl > 0) {
     if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
-    TRY(launch_unembed(c, c->xn + (size_t)lrow0 * E, nl, logits_out, argmax_out, st));
+    TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st));
+    TRY(launch_unembed(c, c->xn, nl, logits_out, argmax_out, st));
   }
   return IXT_OK;
 }
@@ -563,14 +652,14 @@ extern "C" int ixt_prefill_chunk(ixt_ctx* c, int slot, const int32_t* tokens_dev
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_rows_prefill, dim3((n_tokens + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, slot, start_pos, n_tokens);
   LAUNCHCHK();
-  return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, first_token_dev, last_logits_dev, st);
+  return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, first_token_dev, last_logits_dev, false, st);
 }
 
 static int decode_rows(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, hipStream_t st) {
   hipLaunchKernelGGL(k_rows_decode, dim3(1), dim3(c->B <= 1024 ? ((c->B + 63) / 64) * 64 : 1024), 0, st, c->row_slot, c->row_pos, c->row_active, c->row_tok,
                      tokens_dev, pos_dev, c->ps.has_active_page, c->B);
   LAUNCHCHK();
-  return forward_rows(c, c->B, c->row_tok, c->Tmax, 0, c->B, next_tokens_dev, logits_dev, st);
+  return forward_rows(c, c->B, c->row_tok, c->Tmax, 0, c->B, next_tokens_dev, logits_dev, true, st);
 }
 
 extern "C" int ixt_decode_step(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, void* stream) {

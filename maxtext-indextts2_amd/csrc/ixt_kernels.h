@@ -27,7 +27,35 @@ struct DotArgs {
   int groups_per_block;  // SPLIT: groups handled by one block (blockIdx.y picks the range)
   float* amax_val = nullptr;     // EPI 1: [R][ntiles]
   int32_t* amax_idx = nullptr;   // EPI 1: [R][ntiles]
+  int xmode = 0;
 };
+
+// Sum of partial slices in slice order, with the loads of up to U slices issued together (the adds stay
+// sequential; padding with +0.0f is exact because a running sum that started at +0.0f is never -0.0f).
+template <int U>
+__device__ __forceinline__ float sum_slices(const float* p, size_t stride, int slices) {
+  float t = 0.0f;
+  for (int s0 = 0; s0 < slices; s0 += U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? p[(size_t)(s0 + u) * stride] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < U; ++u) t = t + v[u];
+  }
+  return t;
+}
+template <int U>
+__device__ __forceinline__ float2 sum_slices2(const float* p, size_t stride, int slices) {
+  float2 t = make_float2(0.0f, 0.0f);
+  for (int s0 = 0; s0 < slices; s0 += U) {
+    float2 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? *reinterpret_cast<const float2*>(p + (size_t)(s0 + u) * stride) : make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int u = 0; u < U; ++u) { t.x = t.x + v[u].x; t.y = t.y + v[u].y; }
+  }
+  return t;
+}
 
 template <int LW> struct WVec;
 template <> struct WVec<8> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
@@ -46,18 +74,26 @@ __device__ __forceinline__ void unpack_w(const typename WVec<LW>::type& v, float
   }
 }
 
+// Optional producers of x (the activation operand), evaluated by the lanes of each wave for the 16 k x RH rows it
+// is about to consume (one value per lane) and broadcast with v_readlane:
+//   XMODE 0  x is a bf16 matrix, read with scalar loads
+//   XMODE 1  x = RMSNorm(h) * scale (normalizations.py:57-70) from h and the canonical block sums of h^2 (k_sumres_blk)
+//   XMODE 2  x = bf16(sum over attention super-block partials)  (the tail of ref_ragged_paged_attention)
+struct DotX {
+  const bf16_t* h; const float* chunk; int nchunks; int nblk; const bf16_t* scale; float eps;          // XMODE 1 (chunk = [R][E/8] sums of squares)
+  const float* pvpart; const int32_t* row_pos; const int32_t* row_active; int nq, hd, P, nsb_max;    // XMODE 2
+};
+
 // LW = columns per lane (8: 16-B loads, tile 512 columns; 4: 8-B loads, tile 256; 2: 4-B loads, tile 128) -- a pure
 // parallelisation choice for matrices with few column tiles; the numerics do not depend on it.
-// x is wave-uniform per (row, k): it is read with scalar loads (8 dwords = this wave's 16 k of one row) and fed to
-// v_fma as an SGPR operand, so it costs no VGPRs and no LDS.
 // EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded
 // to bf16, optionally stored as f32 logits, and each block emits its (max, first index) pair per row for k_argmax_final.
-template <int RB, int LW, bool SPLIT, bool NT, int EPI>
+template <int RB, int LW, bool SPLIT, int XMODE, int EPI, bool NT>
 __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, int K, int N, int R,
                                                 float* __restrict__ out, int groups_per_block, float* __restrict__ amax_val,
-                                                int32_t* __restrict__ amax_idx) {
+                                                int32_t* __restrict__ amax_idx, DotX xa) {
   typedef typename WVec<LW>::type wvec_t;
-  constexpr int RH = RB < 4 ? RB : 4;  // rows per accumulate/exchange pass
+  constexpr int RH = (LW == 8 && RB > 4) ? 4 : RB;  // rows per accumulate/exchange pass (8 rows x 8 columns would not fit 128 VGPRs)
   constexpr int TW = 64 * LW;          // tile width
   constexpr int NP = 512 / TW;         // threads per column in the exchange
   __shared__ __attribute__((aligned(16))) float red[8 * RH * TW];
@@ -83,11 +119,13 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
     wvec_t wv[IXT_CL];
     if (col_ok) {
       const bf16_t* wp = w + (size_t)kbase * N + nl;
+      // NT: weights of a decode step are read exactly once per step -> non-temporal, so they do not evict the partial
+      // slices and activations the next kernels re-read from L2 / Infinity Cache
 #pragma unroll
       for (int kk = 0; kk < IXT_CL; ++kk) {
-        const wvec_t* p = reinterpret_cast<const wvec_t*>(wp + (size_t)kk * N);
-        if (NT) wv[kk] = __builtin_nontemporal_load(p);
-        else wv[kk] = *p;
+        const wvec_t* pw = reinterpret_cast<const wvec_t*>(wp + (size_t)kk * N);
+        if constexpr (NT) wv[kk] = __builtin_nontemporal_load(pw);
+        else wv[kk] = *pw;
       }
     } else {
 #pragma unroll
@@ -95,14 +133,61 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
     }
 #pragma unroll
     for (int hh = 0; hh < RB / RH; ++hh) {
-      // this wave's 16 x values of each row of the pass: 8 scalar dwords per row (rows past R re-read row R-1; never stored)
-      uint32_t xw[RH][IXT_CL / 2];
+      // ---- x for this pass
+      uint32_t xw[RH][IXT_CL / 2];   // XMODE 0: 8 scalar dwords per row = this wave's 16 k (rows past R re-read row R-1; never stored)
+      float xl[(RH + 3) / 4];        // XMODE 1/2: lane (rr = lane/16, kk = lane%16) holds x[row 4*i + rr of the pass][kbase + kk] in xl[i]
+      if constexpr (XMODE == 0) {
 #pragma unroll
-      for (int r = 0; r < RH; ++r) {
-        const int row = min(r0 + hh * RH + r, R - 1);
-        const uint32_t* xr = reinterpret_cast<const uint32_t*>(x + (size_t)row * ldx + kbase);
+        for (int r = 0; r < RH; ++r) {
+          const int row = min(r0 + hh * RH + r, R - 1);
+          const uint32_t* xr = reinterpret_cast<const uint32_t*>(x + (size_t)row * ldx + kbase);
 #pragma unroll
-        for (int i = 0; i < IXT_CL / 2; ++i) xw[r][i] = xr[i];
+          for (int i = 0; i < IXT_CL / 2; ++i) xw[r][i] = xr[i];
+        }
+      } else {
+        const int kq = kbase + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < (RH + 3) / 4; ++i) xl[i] = 0.0f;
+        if constexpr (XMODE == 1) {
+          // the butterfly needs all 64 lanes: rows are processed one at a time (wave-uniform), lane = chunk-in-block
+          float rs_mine[(RH + 3) / 4];
+#pragma unroll
+          for (int i = 0; i < (RH + 3) / 4; ++i) rs_mine[i] = 0.0f;
+#pragma unroll
+          for (int rr = 0; rr < RH; ++rr) {
+            const int row = min(r0 + hh * RH + rr, R - 1);
+            float sq = 0.0f;
+            for (int bb = 0; bb < xa.nblk; ++bb) {
+              const int ch = bb * 64 + lane;
+              float v = (ch < xa.nchunks) ? xa.chunk[(size_t)row * xa.nchunks + ch] : 0.0f;
+#pragma unroll
+              for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+              sq = sq + v;
+            }
+            const float rs = 1.0f / sqrtf(sq / (float)K + xa.eps);
+            if ((lane >> 4) == (rr & 3)) rs_mine[rr >> 2] = rs;
+          }
+#pragma unroll
+          for (int i = 0; i < (RH + 3) / 4; ++i) {
+            const int rr = i * 4 + (lane >> 4);
+            if (rr < RH) {
+              const int row = min(r0 + hh * RH + rr, R - 1);
+              xl[i] = rbf(rbf(bf2f(xa.h[(size_t)row * K + kq]) * rs_mine[i]) * bf2f(xa.scale[kq]));
+            }
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < (RH + 3) / 4; ++i) {
+            const int rr = i * 4 + (lane >> 4);
+            if (rr < RH) {
+              const int row = min(r0 + hh * RH + rr, R - 1);
+              const int kv_len = xa.row_active[row] ? xa.row_pos[row] + 1 : 0;
+              const int nsb = ((kv_len + xa.P - 1) / xa.P + IXT_SB - 1) / IXT_SB;
+              const int head = kq / xa.hd, d = kq % xa.hd;
+              xl[i] = rbf(sum_slices<8>(xa.pvpart + (((size_t)row * xa.nq + head) * xa.nsb_max) * xa.hd + d, (size_t)xa.hd, nsb));
+            }
+          }
+        }
       }
       float acc[RH][LW];
 #pragma unroll
@@ -115,7 +200,9 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
         unpack_w<LW>(wv[kk], wf);
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
-          const float xv = (kk & 1) ? bfhi(xw[r][kk >> 1]) : bflo(xw[r][kk >> 1]);
+          float xv;
+          if constexpr (XMODE == 0) xv = (kk & 1) ? bfhi(xw[r][kk >> 1]) : bflo(xw[r][kk >> 1]);
+          else xv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl[r >> 2]), (r & 3) * 16 + kk));
 #pragma unroll
           for (int j = 0; j < LW; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
         }
@@ -218,33 +305,6 @@ __global__ __launch_bounds__(256) void k_argmax_final(const float* amax_val, con
   if (tid == 0) out_idx[r] = bi[0] == 0x7fffffff ? 0 : bi[0];
 }
 
-// Sum of partial slices in slice order, with the loads of up to U slices issued together (the adds stay
-// sequential; padding with +0.0f is exact because a running sum that started at +0.0f is never -0.0f).
-template <int U>
-__device__ __forceinline__ float sum_slices(const float* p, size_t stride, int slices) {
-  float t = 0.0f;
-  for (int s0 = 0; s0 < slices; s0 += U) {
-    float v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? p[(size_t)(s0 + u) * stride] : 0.0f;
-#pragma unroll
-    for (int u = 0; u < U; ++u) t = t + v[u];
-  }
-  return t;
-}
-template <int U>
-__device__ __forceinline__ float2 sum_slices2(const float* p, size_t stride, int slices) {
-  float2 t = make_float2(0.0f, 0.0f);
-  for (int s0 = 0; s0 < slices; s0 += U) {
-    float2 v[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) v[u] = (s0 + u < slices) ? *reinterpret_cast<const float2*>(p + (size_t)(s0 + u) * stride) : make_float2(0.0f, 0.0f);
-#pragma unroll
-    for (int u = 0; u < U; ++u) { t.x = t.x + v[u].x; t.y = t.y + v[u].y; }
-  }
-  return t;
-}
-
 // h_out = bf16(h_in + bf16(sum of slices))  (llama2.py:127, :157).  grid = (ceil(E/256), R), block 128, 2 columns per thread.
 __global__ __launch_bounds__(128) void k_sumres(const float* part, int slices, size_t slice_stride, const bf16_t* h_in, bf16_t* h_out, int E) {
   const int c = (blockIdx.x * 128 + threadIdx.x) * 2, r = blockIdx.y;
@@ -253,6 +313,35 @@ __global__ __launch_bounds__(128) void k_sumres(const float* part, int slices, s
   const uint32_t hv = *reinterpret_cast<const uint32_t*>(h_in + (size_t)r * E + c);
   const bf16_t a = f2bf(bflo(hv) + rbf(o.x)), b = f2bf(bfhi(hv) + rbf(o.y));
   *reinterpret_cast<uint32_t*>(h_out + (size_t)r * E + c) = pack2(a, b);
+}
+
+// h_out = bf16(h_in + bf16(sum of slices)) AND the per-chunk sums of squares of h_out (chunk = 8 consecutive elements,
+// one fma chain -- the first level of the canonical RMSNorm reduction; the consumer finishes it).
+// grid = (ceil(E/128), R), block 64: thread t owns 2 columns; chunk = 4 consecutive threads.
+__global__ __launch_bounds__(64) void k_sumres_chunk(const float* part, int slices, size_t slice_stride, const bf16_t* h_in, bf16_t* h_out,
+                                                     float* chunk, int E) {
+  const int r = blockIdx.y, t = threadIdx.x;
+  const int c = blockIdx.x * 128 + t * 2;
+  float h0 = 0.0f, h1 = 0.0f;
+  if (c < E) {
+    const float2 o = sum_slices2<16>(part + (size_t)r * E + c, slice_stride, slices);
+    const uint32_t hv = *reinterpret_cast<const uint32_t*>(h_in + (size_t)r * E + c);
+    h0 = rbf(bflo(hv) + rbf(o.x));
+    h1 = rbf(bfhi(hv) + rbf(o.y));
+    *reinterpret_cast<uint32_t*>(h_out + (size_t)r * E + c) = pack2(f2bf(h0), f2bf(h1));
+  }
+  // chain over the chunk's 8 elements in order: thread q of the chunk continues the chain of thread q-1
+  float a = 0.0f;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float prev = __shfl_up(a, 1, 64);
+    if ((t & 3) == q) {
+      if (q > 0) a = prev;
+      a = __builtin_fmaf(h0, h0, a);
+      a = __builtin_fmaf(h1, h1, a);
+    }
+  }
+  if ((t & 3) == 3 && c < E) chunk[(size_t)r * (E / 8) + c / 8] = a;
 }
 
 // =====================================================================================================
@@ -506,6 +595,110 @@ __global__ __launch_bounds__(256) void k_attn_scores(ScoreArgs a) {
         s = __builtin_fmaf(qb.x, kf[4], s); s = __builtin_fmaf(qb.y, kf[5], s);
         s = __builtin_fmaf(qb.z, kf[6], s); s = __builtin_fmaf(qb.w, kf[7], s);
         acc[q] = s;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) a.scores[((size_t)r * g.nq + kvh * GQ + q) * g.Tmax + j] = acc[q];
+  }
+}
+
+// ---- steps 1+2 fused for decode rows (one new token per row): each block sums the q (and k) slices it needs, applies RoPE,
+//      and computes the scores of its key range; the key of the new token is taken from LDS, never from the page another
+//      block is writing.  Block z == 0 also writes the row's K and V into its page.  grid = (R, nkv, nsplit), block 256.
+struct FrontArgs {
+  const float* part; int slices; size_t slice_stride; int ncols;
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
+  const bf16_t* rope_sin; const bf16_t* rope_cos;
+  bf16_t* kpages; bf16_t* vpages;
+  float* scores;
+  AttnGeom g;
+};
+
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_front_decode(FrontArgs a) {
+  __shared__ __attribute__((aligned(16))) float qs[GQ * HD];
+  __shared__ __attribute__((aligned(16))) float kn[HD];
+  const AttnGeom& g = a.g;
+  const int r = blockIdx.x, kvh = blockIdx.y, sp = blockIdx.z;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (!a.row_active[r]) return;
+  const int pos = a.row_pos[r];
+  const int kv_len = pos + 1;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;
+  if ((sp * 4) * ppw >= pages) return;
+  constexpr int half = HD / 2;
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+  const int QN = g.nq * HD, KN = g.nkv * HD;
+  const int npairs = (GQ + 1 + (sp == 0 ? 1 : 0)) * half;
+  for (int idx = tid; idx < npairs; idx += 256) {
+    const int which = idx / half, i = idx % half;   // 0..GQ-1: q heads, GQ: k, GQ+1: v
+    int col0;
+    if (which < GQ) col0 = (kvh * GQ + which) * HD;
+    else if (which == GQ) col0 = QN + kvh * HD;
+    else col0 = QN + KN + kvh * HD;
+    const float* pq = a.part + (size_t)r * a.ncols + col0;
+    float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
+    float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+    if (which <= GQ) {
+      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
+      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
+      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
+      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      v1 = o1; v2 = o2;
+    }
+    if (which < GQ) {
+      qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+    } else if (which == GQ) {
+      kn[i] = v1; kn[half + i] = v2;
+      if (sp == 0) {
+        const int page = prow[pos / g.P], tok = pos % g.P;
+        a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
+        a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+      }
+    } else {
+      const int page = prow[pos / g.P], tok = pos % g.P;
+      bf16_t* vd = a.vpages + vpage_off(g, page, kvh, tok);
+      vd[i] = f2bf(v1); vd[half + i] = f2bf(v2);
+    }
+  }
+  __syncthreads();
+  const int stride = gridDim.z * 4;
+  for (int ps = sp * 4 + wave; ps * ppw < pages; ps += stride) {
+    const int pidx = ps * ppw + lane / g.P;
+    const int tok = lane % g.P;
+    const int j = pidx * g.P + tok;
+    if (j >= kv_len) continue;
+    float acc[GQ];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q) acc[q] = 0.0f;
+    if (j == pos) {
+#pragma unroll 8
+      for (int d = 0; d < HD; ++d) {
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);
+      }
+    } else {
+      const int page = prow[pidx];
+      const bf16_t* kp = a.kpages + kpage_off(g, page, kvh, 0, tok);
+      u32x4 kv[HD / 8];
+#pragma unroll
+      for (int dc = 0; dc < HD / 8; ++dc) kv[dc] = *reinterpret_cast<const u32x4*>(kp + (size_t)dc * g.P * 8);
+#pragma unroll
+      for (int dc = 0; dc < HD / 8; ++dc) {
+        const float kf[8] = {bflo(kv[dc].x), bfhi(kv[dc].x), bflo(kv[dc].y), bfhi(kv[dc].y),
+                             bflo(kv[dc].z), bfhi(kv[dc].z), bflo(kv[dc].w), bfhi(kv[dc].w)};
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+          const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8);
+          const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8 + 4);
+          float sacc = acc[q];
+          sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);
+          sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);
+          sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);
+          sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);
+          acc[q] = sacc;
+        }
       }
     }
 #pragma unroll
