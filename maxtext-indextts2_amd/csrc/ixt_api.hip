@@ -63,8 +63,8 @@ struct ixt_ctx {
   float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   size_t amax_cap = 0;
-  float* chunk = nullptr;  // [R][E/8] chunk sums of squares of the current residual stream
-  int nblk = 0;
+  bf16_t* xt_op = nullptr;  // op-level entry points: k-major copy of the caller's row-major x
+  size_t xt_cap = 0;
   size_t part_floats = 0;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_tok = nullptr, *new_tok = nullptr;
   AttnGeom geom{};
@@ -186,10 +186,11 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   // workspaces
   A(dmalloc(x, &x->h_a, (size_t)R * E));
   A(dmalloc(x, &x->h_b, (size_t)R * E));
-  A(dmalloc(x, &x->xn, (size_t)R * E));
+  const size_t Rp = (size_t)((R + 15) / 16) * 16;  // k-major activations are padded to whole 16-row blocks
+  A(dmalloc(x, &x->xn, Rp * E));
   A(dmalloc(x, &x->qbuf, (size_t)R * x->QN));
-  A(dmalloc(x, &x->ao, (size_t)R * x->QN));
-  A(dmalloc(x, &x->hact, (size_t)R * F));
+  A(dmalloc(x, &x->ao, Rp * x->QN));
+  A(dmalloc(x, &x->hact, Rp * F));
   {
     // partial slices: SPLIT launches write K/128 slices of [R<=8][N]; FULL launches one slice of [R][N]
     size_t nmax = (size_t)x->NQKV > (size_t)2 * F ? x->NQKV : (size_t)2 * F;
@@ -207,8 +208,11 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 127) / 128);
   A(dmalloc(x, &x->amax_val, x->amax_cap));
   A(dmalloc(x, &x->amax_idx, x->amax_cap));
-  x->nblk = (E / 8 + 63) / 64;
-  A(dmalloc(x, &x->chunk, (size_t)R * (E / 8)));
+  {
+    const int kmax = F > x->QN ? (F > E ? F : E) : (x->QN > E ? x->QN : E);
+    x->xt_cap = (size_t)((R + 15) / 16) * 16 * (kmax > 8192 ? kmax : 8192);
+    A(dmalloc(x, &x->xt_op, x->xt_cap));
+  }
   A(dmalloc(x, &x->row_slot, (size_t)R));
   A(dmalloc(x, &x->row_pos, (size_t)R));
   A(dmalloc(x, &x->row_active, (size_t)R));
@@ -385,89 +389,113 @@ static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
 
 struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
-template <int RB, int LW>
-static void launch_dot_v(const DotArgs& a, const DotX& xa, dim3 grid, bool split, int nt, bool epi, hipStream_t st) {
-#define DOT_GO(S_, X_, E_)                                                                                                             \
-  do {                                                                                                                                 \
-    if (nt) hipLaunchKernelGGL((k_dot<RB, LW, S_, X_, E_, true>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx, xa);  \
-    else hipLaunchKernelGGL((k_dot<RB, LW, S_, X_, E_, false>), grid, dim3(512), 0, st, a.x, a.ldx, a.w, a.K, a.N, a.R, a.out, a.groups_per_block, a.amax_val, a.amax_idx, xa); \
-  } while (0)
-  if (epi) {
-    if (a.xmode == 1) DOT_GO(false, 1, 1); else DOT_GO(false, 0, 1);
-  } else if (split) {
-    if (a.xmode == 1) DOT_GO(true, 1, 0); else if (a.xmode == 2) DOT_GO(true, 2, 0); else DOT_GO(true, 0, 0);
-  } else {
-    if (a.xmode == 1) DOT_GO(false, 1, 0); else if (a.xmode == 2) DOT_GO(false, 2, 0); else DOT_GO(false, 0, 0);
-  }
-#undef DOT_GO
-}
-template <int RB>
-static void launch_dot_rb(const DotArgs& a, const DotX& xa, dim3 grid, int lw, bool split, int nt, bool epi, hipStream_t st) {
-  if (lw == 8) launch_dot_v<RB, 8>(a, xa, grid, split, nt, epi, st);
-  else if (lw == 4) launch_dot_v<RB, 4>(a, xa, grid, split, nt, epi, st);
-  else launch_dot_v<RB, 2>(a, xa, grid, split, nt, epi, st);
-}
-
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
 
-// out: f32 [slices][R][N]; force_full: one slice (level-2 sum inside the block)
-// epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store logits; (max,idx) pairs -> c->amax_*; *res->ntiles set)
-static int launch_dot(ixt_ctx* c, const bf16_t* x, int ldx, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
-                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false, int xmode = 0, const DotX* xa = nullptr) {
+template <int RB, int LW>
+static void launch_dotv_v(const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, float* av, int32_t* ai, dim3 grid, bool split, bool nt,
+                          bool epi, hipStream_t st) {
+#define DOT_GO(S_, E_)                                                                                                      \
+  do {                                                                                                                      \
+    if (nt) hipLaunchKernelGGL((k_dot<RB, LW, S_, E_, true>), grid, dim3(512), 0, st, x, w, K, N, R, out, 1, av, ai);       \
+    else hipLaunchKernelGGL((k_dot<RB, LW, S_, E_, false>), grid, dim3(512), 0, st, x, w, K, N, R, out, 1, av, ai);         \
+  } while (0)
+  if (epi) DOT_GO(false, 1);
+  else if (split) DOT_GO(true, 0);
+  else DOT_GO(false, 0);
+#undef DOT_GO
+}
+template <int RB>
+static void launch_dotv_rb(const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, float* av, int32_t* ai, dim3 grid, int lw, bool split,
+                           bool nt, bool epi, hipStream_t st) {
+  if (lw == 8) launch_dotv_v<RB, 8>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
+  else if (lw == 4) launch_dotv_v<RB, 4>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
+  else launch_dotv_v<RB, 2>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
+}
+
+// x: bf16 in the dot x layout (xidx).  out: f32 [slices][R][N]; force_full: one slice (all groups added inside the block/wave).
+// epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store logits; (max,idx) pairs -> c->amax_*).
+// R <= 8: vector-ALU kernel (8 waves per group, all loads of a block in flight at once); more rows: matrix-core kernel
+// (16 rows per wave for the price of one).
+static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
+                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false) {
   if (K % IXT_GL || N % 8) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 128 or N %% 8");
-  const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
-  const int rowblocks = (R + rb - 1) / rb;
-  const int G = K / IXT_GL;
-  const int tiles8 = (N + 511) / 512;
-  bool split = !force_full && !epi_argmax && (tiles8 * rowblocks < 224) && G > 1;
-  if (split && (size_t)G * R * N > out_floats) split = false;
-  if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
   if (out == nullptr && !epi_argmax) return set_err(IXT_ERR_INVALID, "dot: null output");
-  // columns per lane: widest loads that still give the chip >= ~1.5 blocks per CU
-  static const int lw_env = env_int("IXT_DOT_LW", 0);
-  static const int target = env_int("IXT_DOT_TARGET_BLOCKS", 384);
-  int lw = rb == 8 ? 4 : 8;  // 8 rows x 8 columns of accumulators + 16 x 16-B loads do not fit 128 VGPRs (4 waves/SIMD)
-  if (lw_env == 8 || lw_env == 4 || lw_env == 2) lw = lw_env;
-  else {
-    const long per_tile = (long)rowblocks * (split ? G : 1);
-    while (lw > 2 && (long)((N + 64 * lw - 1) / (64 * lw)) * per_tile < target) lw >>= 1;
+  const int G = K / IXT_GL;
+  static const int mfma_min_rows = env_int("IXT_DOT_MFMA_MIN_ROWS", 9);
+  float* av = nullptr; int32_t* ai = nullptr;
+  int ntiles, slices;
+  const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
+  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 16);
+  if (R < mfma_min_rows || R > mfma_max_rows) {
+    const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
+    const int rowblocks = (R + rb - 1) / rb;
+    const int tiles8 = (N + 511) / 512;
+    bool split = !force_full && !epi_argmax && (tiles8 * rowblocks < 224) && G > 1;
+    if (split && (size_t)G * R * N > out_floats) split = false;
+    if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+    static const int lw_env = env_int("IXT_DOT_LW", 0);
+    static const int target = env_int("IXT_DOT_TARGET_BLOCKS", 384);
+    int lw = rb == 8 ? 4 : 8;  // 8 rows x 8 columns of accumulators + 16 x 16-B loads do not fit 128 VGPRs (4 waves/SIMD)
+    if (lw_env == 8 || lw_env == 4 || lw_env == 2) lw = lw_env;
+    else {
+      const long per_tile = (long)rowblocks * (split ? G : 1);
+      while (lw > 2 && (long)((N + 64 * lw - 1) / (64 * lw)) * per_tile < target) lw >>= 1;
+    }
+    ntiles = (N + 64 * lw - 1) / (64 * lw);
+    if (epi_argmax) {
+      if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+      av = c->amax_val; ai = c->amax_idx;
+    }
+    dim3 grid(ntiles, split ? G : 1, rowblocks);
+    slices = split ? G : 1;
+    const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
+    switch (rb) {
+      case 1: launch_dotv_rb<1>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
+      case 2: launch_dotv_rb<2>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
+      case 4: launch_dotv_rb<4>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
+      default: launch_dotv_rb<8>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
+    }
+    timing_end(c, st, ti);
+  } else {
+    const int rowblocks = (R + 15) / 16;
+    ntiles = (N + 127) / 128;
+    static const int full_units = env_int("IXT_DOT_FULL_UNITS", 1024);
+    bool split = !force_full && !epi_argmax && rowblocks == 1 && ntiles < full_units && G > 1;
+    if (split && (size_t)G * R * N > out_floats) split = false;
+    if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+    if (epi_argmax) {
+      if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+      av = c->amax_val; ai = c->amax_idx;
+    }
+    dim3 grid((ntiles + 3) / 4, split ? G : 1, rowblocks);
+    const bool nt = rowblocks == 1;  // weights read once per launch
+    slices = split ? G : 1;
+    const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
+#define DOTM(S_, E_)                                                                                                                     \
+  do {                                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
+    else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                     \
+  } while (0)
+    if (epi_argmax) DOTM(false, 1);
+    else if (split) DOTM(true, 0);
+    else DOTM(false, 0);
+#undef DOTM
+    timing_end(c, st, ti);
   }
-  const int ntiles = (N + 64 * lw - 1) / (64 * lw);
-  DotArgs a;
-  a.x = x; a.ldx = ldx; a.w = w; a.K = K; a.N = N; a.R = R; a.out = out; a.groups_per_block = 1;
-  if (epi_argmax) {
-    if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
-    a.amax_val = c->amax_val; a.amax_idx = c->amax_idx;
-  }
-  a.xmode = xmode;
-  DotX xz{};
-  if (xa) xz = *xa;
-  dim3 grid(ntiles, split ? G : 1, rowblocks);
-  const int nt = rowblocks == 1 ? 1 : 0;
-  const double bytes = (double)K * N * 2.0 + (double)R * K * 2.0 + (double)(split ? G : 1) * R * N * 4.0;
-  const int ti = timing_begin(c, st, bytes);
-  switch (rb) {
-    case 1: launch_dot_rb<1>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
-    case 2: launch_dot_rb<2>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
-    case 4: launch_dot_rb<4>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
-    default: launch_dot_rb<8>(a, xz, grid, lw, split, nt, epi_argmax, st); break;
-  }
-  timing_end(c, st, ti);
   LAUNCHCHK();
-  res->slices = split ? G : 1;
+  res->slices = slices;
   res->slice_stride = (size_t)R * N;
   res->ntiles = ntiles;
   return IXT_OK;
 }
 
 // logits (optional store) + greedy argmax for R rows of normed hidden states
-static int launch_unembed(ixt_ctx* c, const bf16_t* y, int R, float* logits_out, int32_t* argmax_out, hipStream_t st, int xmode = 0,
-                          const DotX* xa = nullptr) {
+static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
   DotResult dr;
-  TRY(launch_dot(c, y, c->E, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true, xmode, xa));
+  TRY(launch_dot(c, yT, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true));
   hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, dr.ntiles, argmax_out);
   LAUNCHCHK();
   return IXT_OK;
@@ -494,7 +522,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
   pa.pvpart = c->pvpart; pa.g = g;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
-  hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, out, g);
+  hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, out, g, 0);
 }
 
 static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t* qbuf, bf16_t* out, hipStream_t st) {
@@ -505,8 +533,9 @@ static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf
 }
 
 static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, const DotResult* part, const bf16_t* h_in, bf16_t* h_out,
-                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st) {
+                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st, int kmajor = 1) {
   RowNormArgs a;
+  a.xn_kmajor = kmajor;
   a.tokens = tokens; a.embedding = c->embedding; a.part = c->part;
   a.slices = part ? part->slices : 0; a.slice_stride = part ? part->slice_stride : 0;
   a.h_in = h_in; a.h_out = h_out; a.scale = scale; a.xn_out = xn_out; a.E = c->E; a.eps = c->cfg.normalization_layer_epsilon;
@@ -590,8 +619,8 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
 
 // The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
 // Logits are produced for rows [lrow0, lrow0+nl).  decode: one new token per row (rows never read each other's new K).
-// Launches per layer: dot_qkv, [front | qkv_finalize + scores], pv, dot_o (x = combined attention partials), sumres_blk,
-// dot_wi (x = RMSNorm on the fly), swiglu, dot_wo, sumres_blk.
+// Launches per layer: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum + residual + norm),
+// dot_wi, swiglu, dot_wo, sumres, rownorm.
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
@@ -599,20 +628,10 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
   DotResult dr;
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
-  DotX xn{};
-  xn.chunk = c->chunk; xn.nchunks = E / 8; xn.nblk = c->nblk; xn.eps = c->cfg.normalization_layer_epsilon;
-  DotX xc{};
-  xc.pvpart = c->pvpart; xc.row_pos = c->row_pos; xc.row_active = c->row_active; xc.nq = c->Q; xc.hd = c->D; xc.P = c->P; xc.nsb_max = c->nsb_max;
-  // layer 0 input: embedding rows, normalised by the row kernel (no block sums exist yet)
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
-    if (l == 0) {
-      TRY(launch_dot(c, c->xn, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
-    } else {
-      xn.h = hcur; xn.scale = w.ln1;
-      TRY(launch_dot(c, nullptr, E, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr, false, 1, &xn));
-    }
+    TRY(launch_dot(c, c->xn, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
     if (!decode) {
       QkvArgs qa;
       qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
@@ -624,16 +643,17 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       LAUNCHCHK();
     }
     TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));
-    TRY(launch_dot(c, nullptr, c->QN, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr, false, 2, &xc));
-    hipLaunchKernelGGL(k_sumres_chunk, dim3((E + 127) / 128, R), dim3(64), 0, st, c->part, dr.slices, dr.slice_stride, hcur, hnext, c->chunk, E);
+    hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
     LAUNCHCHK();
-    xn.h = hnext; xn.scale = w.ln2;
-    TRY(launch_dot(c, nullptr, E, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr, false, 1, &xn));
+    TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
+    TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
+    TRY(launch_dot(c, c->xn, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
     hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();
-    TRY(launch_dot(c, c->hact, F, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
-    hipLaunchKernelGGL(k_sumres_chunk, dim3((E + 127) / 128, R), dim3(64), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, c->chunk, E);
+    TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
+    hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
     LAUNCHCHK();
+    if (l + 1 < c->L) TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, c->layers[l + 1].ln1, c->xn, st));
   }
   if (nl > 0) {
     if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
@@ -727,24 +747,29 @@ __global__ void k_sum_slices(const float* part, int slices, size_t stride, float
   out[i] = t;
 }
 
+static int transpose_rows(ixt_ctx* c, const bf16_t* x, int R, int K, hipStream_t st) {
+  if ((size_t)((R + 15) / 16) * 16 * K > c->xt_cap) return set_err(IXT_ERR_INVALID, "op: %d rows x %d exceed the scratch of this ctx", R, K);
+  hipLaunchKernelGGL(k_transpose_x, dim3((K + 255) / 256, R), dim3(256), 0, st, x, c->xt_op, R, K);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
 extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream) {
   if (!c || !x || !w || !out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
+  TRY(transpose_rows(c, x, R, K, st));
   DotResult dr;
-  if ((size_t)R * N <= c->part_floats) {
-    TRY(launch_dot(c, x, K, w, K, N, R, c->part, c->part_floats, false, st, &dr));
-    const size_t n = (size_t)R * N;
-    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
-    LAUNCHCHK();
-    return IXT_OK;
-  }
-  return launch_dot(c, x, K, w, K, N, R, out, (size_t)R * N, true, st, &dr);
+  TRY(launch_dot(c, c->xt_op, w, K, N, R, c->part, c->part_floats, false, st, &dr));
+  const size_t n = (size_t)R * N;
+  hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
+  LAUNCHCHK();
+  return IXT_OK;
 }
 
 extern "C" int ixt_op_rmsnorm(ixt_ctx* c, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream) {
   if (!c || !x || !scale || !out || R <= 0 || E % 8) return set_err(IXT_ERR_INVALID, "bad argument");
   RowNormArgs a{};
-  a.h_in = x; a.h_out = nullptr; a.scale = scale; a.xn_out = out; a.E = E; a.eps = c->cfg.normalization_layer_epsilon;
+  a.h_in = x; a.h_out = nullptr; a.scale = scale; a.xn_out = out; a.E = E; a.eps = c->cfg.normalization_layer_epsilon; a.xn_kmajor = 0;
   hipLaunchKernelGGL((k_rownorm<2>), dim3(R), dim3(256), sizeof(float) * ((size_t)E + 64), (hipStream_t)stream, a);
   LAUNCHCHK();
   return IXT_OK;
@@ -787,7 +812,8 @@ extern "C" int ixt_op_unembed_argmax(ixt_ctx* c, const uint16_t* y, int R, float
   if (!c || !y || !argmax || R <= 0 || R > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "bad argument");
   if (!(c->loaded[c->L] & 4)) return set_err(IXT_ERR_NOT_LOADED, "logits_dense/kernel not loaded");
   hipStream_t st = (hipStream_t)stream;
-  return launch_unembed(c, y, R, logits, argmax, st);
+  TRY(transpose_rows(c, y, R, c->E, st));
+  return launch_unembed(c, c->xt_op, R, logits, argmax, st);
 }
 
 extern "C" int ixt_kv_gather(ixt_ctx* c, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream) {

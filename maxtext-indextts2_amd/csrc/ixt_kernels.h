@@ -74,24 +74,178 @@ __device__ __forceinline__ void unpack_w(const typename WVec<LW>::type& v, float
   }
 }
 
-// Optional producers of x (the activation operand), evaluated by the lanes of each wave for the 16 k x RH rows it
-// is about to consume (one value per lane) and broadcast with v_readlane:
-//   XMODE 0  x is a bf16 matrix, read with scalar loads
-//   XMODE 1  x = RMSNorm(h) * scale (normalizations.py:57-70) from h and the canonical block sums of h^2 (k_sumres_blk)
-//   XMODE 2  x = bf16(sum over attention super-block partials)  (the tail of ref_ragged_paged_attention)
-struct DotX {
-  const bf16_t* h; const float* chunk; int nchunks; int nblk; const bf16_t* scale; float eps;          // XMODE 1 (chunk = [R][E/8] sums of squares)
-  const float* pvpart; const int32_t* row_pos; const int32_t* row_active; int nq, hd, P, nsb_max;    // XMODE 2
-};
+// Index of activation element (row r, feature k) in the dot kernel's x layout: [row-block r/16][k/32][k%4][r%16][(k%32)/4].
+// A lane (s = row-in-block, q = k%4) of the MFMA A fragment then finds its 8 values of a 32-k quarter-group in 16 contiguous bytes.
+__host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
+  return (size_t)(r >> 4) * K * 16 + ((((size_t)(k >> 5) * 4 + (k & 3)) * 16 + (r & 15)) * 8 + ((k & 31) >> 2));
+}
 
+// =====================================================================================================
+// Canonical DOT on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate) is bit-for-bit a k-ordered fmaf
+// chain (CDNA4 guide, "FP32-input MFMA"), so it computes exactly the canonical chain while leaving the VALU nearly idle
+// (one shift/and per weight element to widen bf16), and 16 activation rows cost the same as one.
+//   x layout   bf16, see xidx(): per 16-row block and 64-k half-group the A fragments (A[row = lane&15][k = lane>>4]) of
+//              the 16 instructions are laid out so that each lane reads its 16 values as 32 contiguous bytes
+//   a wave     owns 128 columns: lane (s = lane&15, q = lane>>4) loads 16 B = W[k0 + q][n0 + 8s .. +7]; element j feeds MFMA j
+//              as B[k = q][slot = s], i.e. slot s of accumulator j is column n0 + 8s + j; 8 accumulators x 4 VGPRs
+//   chain      16 k = 4 instructions per accumulator (k ascending), started from 0
+//   group      8 chains added in order into grp (VALU adds); SPLIT: grp -> slice g; !SPLIT: tot += grp over all groups
+//   pipeline   the loads of chain c+PD are issued before chain c is consumed (PD chains = PD KiB per lane-row in flight)
+// grid = (ceil(N/512), nsplit, ceil(R/16)), block 256 = 4 independent waves (no LDS, no barrier).
+// EPI = 1 (only !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75).
+// =====================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool SPLIT, int EPI, bool NT>
+__global__ __launch_bounds__(256, 2) void k_dotm(const bf16_t* __restrict__ xT, const bf16_t* __restrict__ w, int K, int N, int R,
+                                              float* __restrict__ out, int groups_per_wave, float* __restrict__ amax_val,
+                                              int32_t* __restrict__ amax_idx, int ntiles) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x * 4 + wave;
+  const int n0 = tile * 128, nl = n0 + s * 8;
+  if (n0 >= N) return;
+  const bool col_ok = nl < N;
+  const int rz = blockIdx.z;
+  const bf16_t* xb = xT + (size_t)rz * K * 16;
+  const int G = K / IXT_GL;
+  int g_begin = 0, g_end = G;
+  if (SPLIT) {
+    g_begin = blockIdx.y * groups_per_wave;
+    g_end = min(G, g_begin + groups_per_wave);
+  }
+  // Two named buffers (A, B), each a QUARTER-GROUP = 2 chains = 32 k: 8 weight loads (16 B) + 1 x load (16 B) per lane, so
+  // a wave keeps 16 KiB of weights in flight.  The loop body (4 chains) is not unrolled further.  (Macros, not lambdas: arrays
+  // captured by reference are not promoted to registers reliably.)
+  u32x4 wA[8], wB[8];
+  u32x4 xA, xB;
+  f32x4 tot[8], grp[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { tot[j] = f32x4(0.0f); grp[j] = f32x4(0.0f); }
+#define IXT_LOAD_Q(WBUF, XBUF, QG)                                                                        \
+  do {                                                                                                    \
+    XBUF = *reinterpret_cast<const u32x4*>(xb + (((size_t)(QG) * 4 + q) * 16 + s) * 8);                  \
+    const bf16_t* wrow_ = w + (size_t)((QG) * 32 + q) * N + nl;                                           \
+    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                                    \
+      const u32x4* pw_ = reinterpret_cast<const u32x4*>(wrow_ + (size_t)(4 * t_) * N);                    \
+      if (!col_ok) WBUF[t_] = u32x4(0);                                                                   \
+      else if constexpr (NT) WBUF[t_] = __builtin_nontemporal_load(pw_);                                  \
+      else WBUF[t_] = *pw_;                                                                               \
+    }                                                                                                     \
+  } while (0)
+#define IXT_CONSUME_Q(WBUF, XBUF)                                                                         \
+  do {                                                                                                    \
+    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                    \
+      f32x4 acc_[8];                                                                                      \
+      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) acc_[j_] = f32x4(0.0f);                            \
+      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
+        const int i_ = c_ * 4 + t_;                                                                       \
+        const uint32_t xd_ = XBUF[i_ >> 1];                                                               \
+        const float a_ = (i_ & 1) ? bfhi(xd_) : bflo(xd_);                                                \
+        const u32x4 wv_ = WBUF[i_];                                                                       \
+        acc_[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.x), acc_[0], 0, 0, 0);                \
+        acc_[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.x), acc_[1], 0, 0, 0);                \
+        acc_[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.y), acc_[2], 0, 0, 0);                \
+        acc_[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.y), acc_[3], 0, 0, 0);                \
+        acc_[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.z), acc_[4], 0, 0, 0);                \
+        acc_[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.z), acc_[5], 0, 0, 0);                \
+        acc_[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.w), acc_[6], 0, 0, 0);                \
+        acc_[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.w), acc_[7], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0); /* one k-step at a time: no hoisting of later unpacks */       \
+      }                                                                                                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) grp[j_] = grp[j_] + acc_[j_];                      \
+    }                                                                                                     \
+  } while (0)
+  const int qg_begin = g_begin * 4, qg_end = g_end * 4;
+  IXT_LOAD_Q(wA, xA, qg_begin);
+  IXT_LOAD_Q(wB, xB, qg_begin + 1);
+#pragma unroll 1
+  for (int qg = qg_begin; qg < qg_end; qg += 2) {
+    IXT_CONSUME_Q(wA, xA);
+    if (qg + 2 < qg_end) IXT_LOAD_Q(wA, xA, qg + 2);
+    IXT_CONSUME_Q(wB, xB);
+    if (qg + 3 < qg_end) IXT_LOAD_Q(wB, xB, qg + 3);
+    if (((qg + 2) & 3) == 0) {   // a group (four quarter-groups) is complete
+      const int g = qg >> 2;
+      if (SPLIT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = rz * 16 + q * 4 + r;
+          if (row < R && col_ok) {
+            float* dst = out + ((size_t)g * R + row) * N + nl;
+            *reinterpret_cast<float4*>(dst) = make_float4(grp[0][r], grp[1][r], grp[2][r], grp[3][r]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(grp[4][r], grp[5][r], grp[6][r], grp[7][r]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) tot[j] = tot[j] + grp[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) grp[j] = f32x4(0.0f);
+    }
+  }
+  if (!SPLIT && EPI == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rz * 16 + q * 4 + r;
+      if (row < R && col_ok) {
+        float* dst = out + (size_t)row * N + nl;
+        *reinterpret_cast<float4*>(dst) = make_float4(tot[0][r], tot[1][r], tot[2][r], tot[3][r]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[4][r], tot[5][r], tot[6][r], tot[7][r]);
+      }
+    }
+  }
+  if (!SPLIT && EPI == 1) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = rz * 16 + q * 4 + r;
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rbf(tot[j][r]);
+      if (row < R && col_ok && out != nullptr) {
+        float* dst = out + (size_t)row * N + nl;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      float best = -INFINITY;
+      int bidx = 0x7fffffff;
+      if (col_ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v[j] > best) { best = v[j]; bidx = nl + j; }   // ascending j: first index wins ties
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {   // lanes with the same q hold the same rows
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      }
+      if (s == 0 && row < R) {
+        amax_val[(size_t)row * ntiles + tile] = best;
+        amax_idx[(size_t)row * ntiles + tile] = bidx;
+      }
+    }
+  }
+}
+
+// =====================================================================================================
+// The same canonical DOT on the vector ALU (v_pk_fma_f32), for <= 8 activation rows per block (decode): at 8 rows the f32
+// matrix pipe gives no advantage (f32 MFMA rate = vector rate, and a 16-row instruction is half empty), while this
+// structure has every load of a block in flight at once and 8 waves per 128-k group.
+//   grid  = (ceil(N/(64 LW)), nsplit, ceil(R/RB));  block = 512 threads = 8 waves = the 8 chains of one group.
+//   wave w owns chain w: 16 k-rows x (64 LW) columns, one load per lane per k-row, LW columns x RB rows of f32 accumulators
+//   per lane; x comes in as SGPR operands (scalar loads).  The 8 chain results are added in chain order through LDS.
+//   SPLIT: every group sum goes to its own slice; !SPLIT: the block walks all groups and adds the group sums in order.
+// =====================================================================================================
 // LW = columns per lane (8: 16-B loads, tile 512 columns; 4: 8-B loads, tile 256; 2: 4-B loads, tile 128) -- a pure
 // parallelisation choice for matrices with few column tiles; the numerics do not depend on it.
 // EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded
 // to bf16, optionally stored as f32 logits, and each block emits its (max, first index) pair per row for k_argmax_final.
-template <int RB, int LW, bool SPLIT, int XMODE, int EPI, bool NT>
-__global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ w, int K, int N, int R,
+template <int RB, int LW, bool SPLIT, int EPI, bool NT>
+__global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int K, int N, int R,
                                                 float* __restrict__ out, int groups_per_block, float* __restrict__ amax_val,
-                                                int32_t* __restrict__ amax_idx, DotX xa) {
+                                                int32_t* __restrict__ amax_idx) {
   typedef typename WVec<LW>::type wvec_t;
   constexpr int RH = (LW == 8 && RB > 4) ? 4 : RB;  // rows per accumulate/exchange pass (8 rows x 8 columns would not fit 128 VGPRs)
   constexpr int TW = 64 * LW;          // tile width
@@ -133,60 +287,18 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
     }
 #pragma unroll
     for (int hh = 0; hh < RB / RH; ++hh) {
-      // ---- x for this pass
-      uint32_t xw[RH][IXT_CL / 2];   // XMODE 0: 8 scalar dwords per row = this wave's 16 k (rows past R re-read row R-1; never stored)
-      float xl[(RH + 3) / 4];        // XMODE 1/2: lane (rr = lane/16, kk = lane%16) holds x[row 4*i + rr of the pass][kbase + kk] in xl[i]
-      if constexpr (XMODE == 0) {
+      // ---- x for this pass: per row 4 scalar 8-byte loads from the dot x layout (xidx): for q = k%4 the wave's chain holds
+      //      k = kbase+q, +4, +8, +12 as 4 consecutive bf16 (rows past R re-read row R-1; never stored)
+      uint32_t xw[RH][4][2];
 #pragma unroll
-        for (int r = 0; r < RH; ++r) {
-          const int row = min(r0 + hh * RH + r, R - 1);
-          const uint32_t* xr = reinterpret_cast<const uint32_t*>(x + (size_t)row * ldx + kbase);
+      for (int r = 0; r < RH; ++r) {
+        const int row = min(r0 + hh * RH + r, R - 1);
+        const bf16_t* xr = x + (size_t)(row >> 4) * K * 16 + ((size_t)(kbase >> 5) * 64 + (row & 15)) * 8 + ((kbase >> 4) & 1) * 4;
 #pragma unroll
-          for (int i = 0; i < IXT_CL / 2; ++i) xw[r][i] = xr[i];
-        }
-      } else {
-        const int kq = kbase + (lane & 15);
-#pragma unroll
-        for (int i = 0; i < (RH + 3) / 4; ++i) xl[i] = 0.0f;
-        if constexpr (XMODE == 1) {
-          // the butterfly needs all 64 lanes: rows are processed one at a time (wave-uniform), lane = chunk-in-block
-          float rs_mine[(RH + 3) / 4];
-#pragma unroll
-          for (int i = 0; i < (RH + 3) / 4; ++i) rs_mine[i] = 0.0f;
-#pragma unroll
-          for (int rr = 0; rr < RH; ++rr) {
-            const int row = min(r0 + hh * RH + rr, R - 1);
-            float sq = 0.0f;
-            for (int bb = 0; bb < xa.nblk; ++bb) {
-              const int ch = bb * 64 + lane;
-              float v = (ch < xa.nchunks) ? xa.chunk[(size_t)row * xa.nchunks + ch] : 0.0f;
-#pragma unroll
-              for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
-              sq = sq + v;
-            }
-            const float rs = 1.0f / sqrtf(sq / (float)K + xa.eps);
-            if ((lane >> 4) == (rr & 3)) rs_mine[rr >> 2] = rs;
-          }
-#pragma unroll
-          for (int i = 0; i < (RH + 3) / 4; ++i) {
-            const int rr = i * 4 + (lane >> 4);
-            if (rr < RH) {
-              const int row = min(r0 + hh * RH + rr, R - 1);
-              xl[i] = rbf(rbf(bf2f(xa.h[(size_t)row * K + kq]) * rs_mine[i]) * bf2f(xa.scale[kq]));
-            }
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < (RH + 3) / 4; ++i) {
-            const int rr = i * 4 + (lane >> 4);
-            if (rr < RH) {
-              const int row = min(r0 + hh * RH + rr, R - 1);
-              const int kv_len = xa.row_active[row] ? xa.row_pos[row] + 1 : 0;
-              const int nsb = ((kv_len + xa.P - 1) / xa.P + IXT_SB - 1) / IXT_SB;
-              const int head = kq / xa.hd, d = kq % xa.hd;
-              xl[i] = rbf(sum_slices<8>(xa.pvpart + (((size_t)row * xa.nq + head) * xa.nsb_max) * xa.hd + d, (size_t)xa.hd, nsb));
-            }
-          }
+        for (int qq = 0; qq < 4; ++qq) {
+          const uint32_t* p2 = reinterpret_cast<const uint32_t*>(xr + (size_t)qq * 128);
+          xw[r][qq][0] = p2[0];
+          xw[r][qq][1] = p2[1];
         }
       }
       float acc[RH][LW];
@@ -200,9 +312,8 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
         unpack_w<LW>(wv[kk], wf);
 #pragma unroll
         for (int r = 0; r < RH; ++r) {
-          float xv;
-          if constexpr (XMODE == 0) xv = (kk & 1) ? bfhi(xw[r][kk >> 1]) : bflo(xw[r][kk >> 1]);
-          else xv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(xl[r >> 2]), (r & 3) * 16 + kk));
+          const uint32_t xd = xw[r][kk & 3][kk >> 3];
+          const float xv = ((kk >> 2) & 1) ? bfhi(xd) : bflo(xd);
 #pragma unroll
           for (int j = 0; j < LW; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
         }
@@ -279,6 +390,12 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, in
       }
     }
   }
+}
+
+// x [R][K] row-major bf16 -> the dot kernel's x layout (op-level entry point only; the model's producers write it directly)
+__global__ void k_transpose_x(const bf16_t* x, bf16_t* xT, int R, int K) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
+  if (k < K) xT[xidx(r, k, K)] = x[(size_t)r * K + k];
 }
 
 // final (max, first index) over the per-tile pairs.  grid = R, block 256.
@@ -361,6 +478,7 @@ struct RowNormArgs {
   const bf16_t* scale;
   bf16_t* xn_out;
   int E; float eps;
+  int xn_kmajor;   // 1: write xn as [row-block][E][16] (the dot kernel's x layout), 0: [R][E]
 };
 
 template <int MODE>
@@ -384,12 +502,19 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
         float o[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = 0.0f;
-        for (int s = 0; s < a.slices; ++s) {
-          const float* p = a.part + (size_t)s * a.slice_stride + (size_t)r * E + ch * 8;
-          const float4 p0 = *reinterpret_cast<const float4*>(p);
-          const float4 p1 = *reinterpret_cast<const float4*>(p + 4);
-          o[0] = o[0] + p0.x; o[1] = o[1] + p0.y; o[2] = o[2] + p0.z; o[3] = o[3] + p0.w;
-          o[4] = o[4] + p1.x; o[5] = o[5] + p1.y; o[6] = o[6] + p1.z; o[7] = o[7] + p1.w;
+        for (int s0 = 0; s0 < a.slices; s0 += 8) {
+          float4 p0[8], p1[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float* p = a.part + (size_t)(s0 + u) * a.slice_stride + (size_t)r * E + ch * 8;
+            p0[u] = (s0 + u < a.slices) ? *reinterpret_cast<const float4*>(p) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            p1[u] = (s0 + u < a.slices) ? *reinterpret_cast<const float4*>(p + 4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            o[0] = o[0] + p0[u].x; o[1] = o[1] + p0[u].y; o[2] = o[2] + p0[u].z; o[3] = o[3] + p0[u].w;
+            o[4] = o[4] + p1[u].x; o[5] = o[5] + p1[u].y; o[6] = o[6] + p1[u].z; o[7] = o[7] + p1[u].w;
+          }
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[j] = rbf(h[j] + rbf(o[j]));
@@ -426,9 +551,14 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
     bf16_t o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f2bf(rbf(hrow[ch * 8 + j] * rs) * sc[j]);
-    u32x4 ov;
-    ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
-    *reinterpret_cast<u32x4*>(a.xn_out + (size_t)r * E + ch * 8) = ov;
+    if (a.xn_kmajor) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a.xn_out[xidx(r, ch * 8 + j, E)] = o[j];
+    } else {
+      u32x4 ov;
+      ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+      *reinterpret_cast<u32x4*>(a.xn_out + (size_t)r * E + ch * 8) = ov;
+    }
   }
 }
 
@@ -443,7 +573,7 @@ __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slic
   const float* p = part + (size_t)r * 2 * F;
   const float a = sum_slices<16>(p + f, slice_stride, slices);
   const float b = sum_slices<16>(p + F + f, slice_stride, slices);
-  out[(size_t)r * F + f] = ixt_swiglu(rbf(a), rbf(b));
+  out[xidx(r, f, F)] = ixt_swiglu(rbf(a), rbf(b));   // x layout of the dot kernel
 }
 
 __global__ __launch_bounds__(256) void k_swiglu(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
@@ -820,7 +950,7 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
 
 // ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const int32_t* row_pos, const int32_t* row_active,
-                                                      bf16_t* out, AttnGeom g) {
+                                                      bf16_t* out, AttnGeom g, int kmajor) {
   const int r = blockIdx.x;
   const int kv_len = row_active[r] ? row_pos[r] + 1 : 0;
   const int pages = (kv_len + g.P - 1) / g.P;
@@ -829,7 +959,8 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const
   for (int i = threadIdx.x; i < n; i += 256) {
     const int h = i / g.hd, d = i % g.hd;
     const float t = sum_slices<8>(pvpart + (((size_t)r * g.nq + h) * g.nsb_max) * g.hd + d, (size_t)g.hd, nsb);
-    out[(size_t)r * n + i] = f2bf(t);
+    if (kmajor) out[xidx(r, i, n)] = f2bf(t);
+    else out[(size_t)r * n + i] = f2bf(t);
   }
 }
 
