@@ -470,14 +470,20 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
       av = c->amax_val; ai = c->amax_idx;
     }
-    dim3 grid((ntiles + 3) / 4, split ? G : 1, rowblocks);
+    static const int use_dotg = env_int("IXT_DOT_G", 1);
+    dim3 grid(use_dotg ? ntiles : (ntiles + 3) / 4, split ? G : 1, rowblocks);
     const bool nt = rowblocks == 1;  // weights read once per launch
     slices = split ? G : 1;
     const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
 #define DOTM(S_, E_)                                                                                                                     \
   do {                                                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
-    else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                     \
+    if (use_dotg) {                                                                                                                      \
+      if (nt) hipLaunchKernelGGL((k_dotg<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                    \
+      else hipLaunchKernelGGL((k_dotg<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                      \
+    } else {                                                                                                                             \
+      if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                 \
+      else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
+    }                                                                                                                                    \
   } while (0)
     if (epi_argmax) DOTM(false, 1);
     else if (split) DOTM(true, 0);

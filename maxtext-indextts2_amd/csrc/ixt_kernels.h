@@ -392,6 +392,145 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, co
   }
 }
 
+// =====================================================================================================
+// Matrix-core DOT, one memory round trip per group: block = 4 waves = one 128-k group x 128 columns; wave v owns chains
+// 2v, 2v+1 (32 k): its 8 weight loads + 1 x load are all issued before the first MFMA; the 8 chain results of the group are
+// exchanged through LDS and added in chain order (thread t owns row t/16, columns 8(t%16)..+7).
+// grid = (ceil(N/128), nsplit, ceil(R/16)), block 256, LDS 64 KiB.
+// =====================================================================================================
+template <bool SPLIT, int EPI, bool NT>
+__global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, const bf16_t* __restrict__ w, int K, int N, int R,
+                                                 float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
+                                                 int ntiles) {
+  // (an exchange of 8 rows at a time in 32 KiB -- four blocks per CU -- measured slower: the extra barriers cost more than the occupancy buys)
+  __shared__ __attribute__((aligned(16))) float red[8 * 16 * 128];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int s = lane & 15, q = lane >> 4;
+  const int tile = blockIdx.x;
+  const int n0 = tile * 128, nl = n0 + s * 8;
+  const bool col_ok = nl < N;
+  const int rz = blockIdx.z;
+  const bf16_t* xb = xT + (size_t)rz * K * 16;
+  const int G = K / IXT_GL;
+  int g_begin = 0, g_end = G;
+  if (SPLIT) { g_begin = blockIdx.y; g_end = g_begin + 1; }
+  // reducer role
+  const int orow = tid >> 4, ocol = (tid & 15) * 8;
+  float tot[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) tot[j] = 0.0f;
+
+  u32x4 wq[8];
+  u32x4 xq;
+#define IXT_LOAD_G(G_)                                                                                    \
+  do {                                                                                                    \
+    const int qg_ = (G_) * 4 + wave;   /* quarter-group = this wave's 2 chains */                         \
+    xq = *reinterpret_cast<const u32x4*>(xb + (((size_t)qg_ * 4 + q) * 16 + s) * 8);                     \
+    const bf16_t* wrow_ = w + (size_t)(qg_ * 32 + q) * N + nl;                                            \
+    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                                    \
+      const u32x4* pw_ = reinterpret_cast<const u32x4*>(wrow_ + (size_t)(4 * t_) * N);                    \
+      if (!col_ok) wq[t_] = u32x4(0);                                                                     \
+      else if constexpr (NT) wq[t_] = __builtin_nontemporal_load(pw_);                                    \
+      else wq[t_] = *pw_;                                                                                 \
+    }                                                                                                     \
+  } while (0)
+  IXT_LOAD_G(g_begin);
+  for (int g = g_begin; g < g_end; ++g) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      f32x4 acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = f32x4(0.0f);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = c * 4 + t;
+        const uint32_t xd = xq[i >> 1];
+        const float a = (i & 1) ? bfhi(xd) : bflo(xd);
+        const u32x4 wv = wq[i];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.x), acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.x), acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.y), acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.y), acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.z), acc[4], 0, 0, 0);
+        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.z), acc[5], 0, 0, 0);
+        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.w), acc[6], 0, 0, 0);
+        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.w), acc[7], 0, 0, 0);
+      }
+      // chain (2*wave + c) -> red[chain][row][col]
+      float* dst = red + ((size_t)(wave * 2 + c) * 16) * 128 + s * 8;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* d2 = dst + (q * 4 + r) * 128;
+        *reinterpret_cast<float4*>(d2) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+        *reinterpret_cast<float4*>(d2 + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+      }
+    }
+    if (g + 1 < g_end) IXT_LOAD_G(g + 1);   // next group's loads fly during the exchange
+    __syncthreads();
+    float sum[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum[j] = 0.0f;
+#pragma unroll
+    for (int c = 0; c < IXT_NC; ++c) {
+      const float* src = red + ((size_t)c * 16 + orow) * 128 + ocol;
+      const float4 a0 = *reinterpret_cast<const float4*>(src);
+      const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
+      sum[0] = sum[0] + a0.x; sum[1] = sum[1] + a0.y; sum[2] = sum[2] + a0.z; sum[3] = sum[3] + a0.w;
+      sum[4] = sum[4] + a1.x; sum[5] = sum[5] + a1.y; sum[6] = sum[6] + a1.z; sum[7] = sum[7] + a1.w;
+    }
+    const int row = rz * 16 + orow;
+    if (SPLIT) {
+      if (row < R && n0 + ocol < N) {
+        float* dst = out + ((size_t)g * R + row) * N + n0 + ocol;
+        *reinterpret_cast<float4*>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tot[j] = tot[j] + sum[j];
+    }
+    if (g + 1 < g_end) __syncthreads();
+  }
+#undef IXT_LOAD_G
+  if (!SPLIT) {
+    const int row = rz * 16 + orow;
+    const bool ok = row < R && n0 + ocol < N;
+    if (EPI == 0) {
+      if (ok) {
+        float* dst = out + (size_t)row * N + n0 + ocol;
+        *reinterpret_cast<float4*>(dst) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[4], tot[5], tot[6], tot[7]);
+      }
+    } else {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = rbf(tot[j]);
+      if (ok && out != nullptr) {
+        float* dst = out + (size_t)row * N + n0 + ocol;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      float best = -INFINITY;
+      int bidx = 0x7fffffff;
+      if (n0 + ocol < N) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (v[j] > best) { best = v[j]; bidx = n0 + ocol + j; }
+      }
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {   // the 16 threads of a row are 16 consecutive lanes
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+      }
+      if ((tid & 15) == 0 && row < R) {
+        amax_val[(size_t)row * ntiles + tile] = best;
+        amax_idx[(size_t)row * ntiles + tile] = bidx;
+      }
+    }
+  }
+}
+
 // x [R][K] row-major bf16 -> the dot kernel's x layout (op-level entry point only; the model's producers write it directly)
 __global__ void k_transpose_x(const bf16_t* x, bf16_t* xT, int R, int K) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x, r = blockIdx.y;
