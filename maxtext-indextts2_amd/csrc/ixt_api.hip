@@ -428,7 +428,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   float* av = nullptr; int32_t* ai = nullptr;
   int ntiles, slices;
   const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
-  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 16);
+  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 64);
   if (R < mfma_min_rows || R > mfma_max_rows) {
     const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
     const int rowblocks = (R + rb - 1) / rb;
@@ -462,33 +462,48 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   } else {
     const int rowblocks = (R + 15) / 16;
     ntiles = (N + 127) / 128;
+    static const int use_dotg = env_int("IXT_DOT_G", 1);
     static const int full_units = env_int("IXT_DOT_FULL_UNITS", 1024);
-    bool split = !force_full && !epi_argmax && rowblocks == 1 && ntiles < full_units && G > 1;
+    static const int nrb_env = env_int("IXT_DOT_NRB", 0);
+    int nrb = rowblocks >= 3 ? 4 : rowblocks;                      // 16-row blocks sharing one block's loaded weights (1, 2 or 4)
+    if (rowblocks > 4 && (nrb_env == 1 || nrb_env == 2 || nrb_env == 4)) nrb = nrb_env;
+    const int zblocks = (rowblocks + nrb - 1) / nrb;
+    bool split = !force_full && !epi_argmax && zblocks == 1 && ntiles < full_units && G > 1;
+    if (!use_dotg && rowblocks > 1) split = false;
     if (split && (size_t)G * R * N > out_floats) split = false;
     if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
     if (epi_argmax) {
       if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
       av = c->amax_val; ai = c->amax_idx;
     }
-    static const int use_dotg = env_int("IXT_DOT_G", 1);
-    dim3 grid(use_dotg ? ntiles : (ntiles + 3) / 4, split ? G : 1, rowblocks);
-    const bool nt = rowblocks == 1;  // weights read once per launch
+    const bool nt = zblocks == 1;  // weights read once per launch
     slices = split ? G : 1;
     const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
+    if (use_dotg) {
+      dim3 grid(ntiles, split ? G : 1, zblocks);
+#define DOTG(S_, E_, B_)                                                                                                                 \
+  do {                                                                                                                                   \
+    if (nt) hipLaunchKernelGGL((k_dotg<S_, E_, true, B_>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                  \
+    else hipLaunchKernelGGL((k_dotg<S_, E_, false, B_>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                    \
+  } while (0)
+#define DOTG_B(S_, E_) do { if (nrb == 4) DOTG(S_, E_, 4); else if (nrb == 2) DOTG(S_, E_, 2); else DOTG(S_, E_, 1); } while (0)
+      if (epi_argmax) DOTG_B(false, 1);
+      else if (split) DOTG_B(true, 0);
+      else DOTG_B(false, 0);
+#undef DOTG_B
+#undef DOTG
+    } else {
+      dim3 grid((ntiles + 3) / 4, split ? G : 1, rowblocks);
 #define DOTM(S_, E_)                                                                                                                     \
   do {                                                                                                                                   \
-    if (use_dotg) {                                                                                                                      \
-      if (nt) hipLaunchKernelGGL((k_dotg<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                    \
-      else hipLaunchKernelGGL((k_dotg<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                      \
-    } else {                                                                                                                             \
-      if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                 \
-      else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
-    }                                                                                                                                    \
+    if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
+    else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                     \
   } while (0)
-    if (epi_argmax) DOTM(false, 1);
-    else if (split) DOTM(true, 0);
-    else DOTM(false, 0);
+      if (epi_argmax) DOTM(false, 1);
+      else if (split) DOTM(true, 0);
+      else DOTM(false, 0);
 #undef DOTM
+    }
     timing_end(c, st, ti);
   }
   LAUNCHCHK();

@@ -398,7 +398,9 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, co
 // exchanged through LDS and added in chain order (thread t owns row t/16, columns 8(t%16)..+7).
 // grid = (ceil(N/128), nsplit, ceil(R/16)), block 256, LDS 64 KiB.
 // =====================================================================================================
-template <bool SPLIT, int EPI, bool NT>
+// NRB = 16-row blocks handled by one thread block with the SAME loaded weights (1: <= 16 rows, 2: <= 32, 4: <= 64 per
+// blockIdx.z): the weights of a group are loaded once and reused from registers for every row block.
+template <bool SPLIT, int EPI, bool NT, int NRB>
 __global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, const bf16_t* __restrict__ w, int K, int N, int R,
                                                  float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
                                                  int ntiles) {
@@ -409,23 +411,25 @@ __global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, 
   const int tile = blockIdx.x;
   const int n0 = tile * 128, nl = n0 + s * 8;
   const bool col_ok = nl < N;
-  const int rz = blockIdx.z;
-  const bf16_t* xb = xT + (size_t)rz * K * 16;
+  const int rz0 = blockIdx.z * NRB;                       // first 16-row block of this thread block
   const int G = K / IXT_GL;
   int g_begin = 0, g_end = G;
   if (SPLIT) { g_begin = blockIdx.y; g_end = g_begin + 1; }
   // reducer role
   const int orow = tid >> 4, ocol = (tid & 15) * 8;
-  float tot[8];
+  float tot[NRB][8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) tot[j] = 0.0f;
+  for (int b = 0; b < NRB; ++b)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot[b][j] = 0.0f;
 
   u32x4 wq[8];
-  u32x4 xq;
+  u32x4 xq[NRB];
 #define IXT_LOAD_G(G_)                                                                                    \
   do {                                                                                                    \
     const int qg_ = (G_) * 4 + wave;   /* quarter-group = this wave's 2 chains */                         \
-    xq = *reinterpret_cast<const u32x4*>(xb + (((size_t)qg_ * 4 + q) * 16 + s) * 8);                     \
+    _Pragma("unroll") for (int b_ = 0; b_ < NRB; ++b_)                                                    \
+      xq[b_] = ((rz0 + b_) * 16 < R) ? *reinterpret_cast<const u32x4*>(xT + (size_t)(rz0 + b_) * K * 16 + (((size_t)qg_ * 4 + q) * 16 + s) * 8) : u32x4(0); \
     const bf16_t* wrow_ = w + (size_t)(qg_ * 32 + q) * N + nl;                                            \
     _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                                    \
       const u32x4* pw_ = reinterpret_cast<const u32x4*>(wrow_ + (size_t)(4 * t_) * N);                    \
@@ -436,96 +440,110 @@ __global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, 
   } while (0)
   IXT_LOAD_G(g_begin);
   for (int g = g_begin; g < g_end; ++g) {
+    u32x4 wc[8];
+    u32x4 xc[NRB];
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      f32x4 acc[8];
+    for (int t = 0; t < 8; ++t) wc[t] = wq[t];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = f32x4(0.0f);
+    for (int b = 0; b < NRB; ++b) xc[b] = xq[b];
+    if (g + 1 < g_end) IXT_LOAD_G(g + 1);   // next group's loads fly during this group's MFMAs and exchanges
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int i = c * 4 + t;
-        const uint32_t xd = xq[i >> 1];
-        const float a = (i & 1) ? bfhi(xd) : bflo(xd);
-        const u32x4 wv = wq[i];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.x), acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.x), acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.y), acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.y), acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.z), acc[4], 0, 0, 0);
-        acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.z), acc[5], 0, 0, 0);
-        acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.w), acc[6], 0, 0, 0);
-        acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.w), acc[7], 0, 0, 0);
-      }
-      // chain (2*wave + c) -> red[chain][row][col]
-      float* dst = red + ((size_t)(wave * 2 + c) * 16) * 128 + s * 8;
+    for (int b = 0; b < NRB; ++b) {
+      if ((rz0 + b) * 16 < R) {
+        if (b > 0 || g > g_begin) __syncthreads();   // previous readers of red are done
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float* d2 = dst + (q * 4 + r) * 128;
-        *reinterpret_cast<float4*>(d2) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-        *reinterpret_cast<float4*>(d2 + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+        for (int c = 0; c < 2; ++c) {
+          f32x4 acc[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] = f32x4(0.0f);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int i = c * 4 + t;
+            const uint32_t xd = xc[b][i >> 1];
+            const float a = (i & 1) ? bfhi(xd) : bflo(xd);
+            const u32x4 wv = wc[i];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.x), acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.x), acc[1], 0, 0, 0);
+            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.y), acc[2], 0, 0, 0);
+            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.y), acc[3], 0, 0, 0);
+            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.z), acc[4], 0, 0, 0);
+            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.z), acc[5], 0, 0, 0);
+            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.w), acc[6], 0, 0, 0);
+            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.w), acc[7], 0, 0, 0);
+          }
+          // chain (2*wave + c) -> red[chain][row][col]
+          float* dst = red + ((size_t)(wave * 2 + c) * 16) * 128 + s * 8;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float* d2 = dst + (q * 4 + r) * 128;
+            *reinterpret_cast<float4*>(d2) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
+            *reinterpret_cast<float4*>(d2 + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
+          }
+        }
+        __syncthreads();
+        float sum[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < IXT_NC; ++c) {
+          const float* src = red + ((size_t)c * 16 + orow) * 128 + ocol;
+          const float4 a0 = *reinterpret_cast<const float4*>(src);
+          const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
+          sum[0] = sum[0] + a0.x; sum[1] = sum[1] + a0.y; sum[2] = sum[2] + a0.z; sum[3] = sum[3] + a0.w;
+          sum[4] = sum[4] + a1.x; sum[5] = sum[5] + a1.y; sum[6] = sum[6] + a1.z; sum[7] = sum[7] + a1.w;
+        }
+        const int row = (rz0 + b) * 16 + orow;
+        if (SPLIT) {
+          if (row < R && n0 + ocol < N) {
+            float* dst = out + ((size_t)g * R + row) * N + n0 + ocol;
+            *reinterpret_cast<float4*>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
+            *reinterpret_cast<float4*>(dst + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) tot[b][j] = tot[b][j] + sum[j];
+        }
       }
     }
-    if (g + 1 < g_end) IXT_LOAD_G(g + 1);   // next group's loads fly during the exchange
-    __syncthreads();
-    float sum[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) sum[j] = 0.0f;
-#pragma unroll
-    for (int c = 0; c < IXT_NC; ++c) {
-      const float* src = red + ((size_t)c * 16 + orow) * 128 + ocol;
-      const float4 a0 = *reinterpret_cast<const float4*>(src);
-      const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
-      sum[0] = sum[0] + a0.x; sum[1] = sum[1] + a0.y; sum[2] = sum[2] + a0.z; sum[3] = sum[3] + a0.w;
-      sum[4] = sum[4] + a1.x; sum[5] = sum[5] + a1.y; sum[6] = sum[6] + a1.z; sum[7] = sum[7] + a1.w;
-    }
-    const int row = rz * 16 + orow;
-    if (SPLIT) {
-      if (row < R && n0 + ocol < N) {
-        float* dst = out + ((size_t)g * R + row) * N + n0 + ocol;
-        *reinterpret_cast<float4*>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) tot[j] = tot[j] + sum[j];
-    }
-    if (g + 1 < g_end) __syncthreads();
   }
 #undef IXT_LOAD_G
   if (!SPLIT) {
-    const int row = rz * 16 + orow;
-    const bool ok = row < R && n0 + ocol < N;
-    if (EPI == 0) {
-      if (ok) {
-        float* dst = out + (size_t)row * N + n0 + ocol;
-        *reinterpret_cast<float4*>(dst) = make_float4(tot[0], tot[1], tot[2], tot[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[4], tot[5], tot[6], tot[7]);
-      }
-    } else {
-      float v[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rbf(tot[j]);
-      if (ok && out != nullptr) {
-        float* dst = out + (size_t)row * N + n0 + ocol;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      }
-      float best = -INFINITY;
-      int bidx = 0x7fffffff;
-      if (n0 + ocol < N) {
+    for (int b = 0; b < NRB; ++b) {
+      const int row = (rz0 + b) * 16 + orow;
+      const bool ok = row < R && n0 + ocol < N;
+      if (EPI == 0) {
+        if (ok) {
+          float* dst = out + (size_t)row * N + n0 + ocol;
+          *reinterpret_cast<float4*>(dst) = make_float4(tot[b][0], tot[b][1], tot[b][2], tot[b][3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[b][4], tot[b][5], tot[b][6], tot[b][7]);
+        }
+      } else {
+        float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (v[j] > best) { best = v[j]; bidx = n0 + ocol + j; }
-      }
+        for (int j = 0; j < 8; ++j) v[j] = rbf(tot[b][j]);
+        if (ok && out != nullptr) {
+          float* dst = out + (size_t)row * N + n0 + ocol;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        if (n0 + ocol < N) {
 #pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {   // the 16 threads of a row are 16 consecutive lanes
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-      }
-      if ((tid & 15) == 0 && row < R) {
-        amax_val[(size_t)row * ntiles + tile] = best;
-        amax_idx[(size_t)row * ntiles + tile] = bidx;
+          for (int j = 0; j < 8; ++j)
+            if (v[j] > best) { best = v[j]; bidx = n0 + ocol + j; }
+        }
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {   // the 16 threads of a row are 16 consecutive lanes
+          const float ov = __shfl_xor(best, off, 64);
+          const int oi = __shfl_xor(bidx, off, 64);
+          if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if ((tid & 15) == 0 && row < R) {
+          amax_val[(size_t)row * ntiles + tile] = best;
+          amax_idx[(size_t)row * ntiles + tile] = bidx;
+        }
       }
     }
   }
