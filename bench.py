@@ -5,7 +5,7 @@ configs[1], "C2"), data-parallel over N GPUs of one node (one process per GPU, n
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 8) utterances per GPU,
+A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 64) utterances per GPU,
 each a 256-token prompt (4 s reference speech + 128-char text) prefilled into its slot, then
 `--decode-steps` (default 1024) greedy generate calls for all slots.  Tokens counted = generated audio tokens
 including the first one from prefill (decode.py:162-178: T-P generate calls yield T-P+1 tokens per utterance).
@@ -36,7 +36,7 @@ def parse():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2)
   ap.add_argument("--warmup", type=int, default=1)
-  ap.add_argument("--batch", type=int, default=8, help="utterances (decode slots) per GPU")
+  ap.add_argument("--batch", type=int, default=64, help="utterances (decode slots) per GPU")
   ap.add_argument("--decode-steps", type=int, default=1024)
   ap.add_argument("--prefill-len", type=int, default=256)
   ap.add_argument("--model", default="indextts2-1b")
@@ -214,9 +214,19 @@ def main():
     for s in range(B):
       eng.release_pages(s)
     achieved = bpl.value / (avg_us.value * 1e-6) / 1e9 if avg_us.value > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_dot (decode, all launches of a step)", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK / 1e9), "traffic": None, "avg_launch_us": avg_us.value, "launches": int(n.value),
-                "algorithmic_bytes_per_launch": bpl.value}
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+      try:
+        pj = json.load(open(pmc))
+        if pj.get("batch") == B and pj.get("model") == args.model:
+          traffic, traffic_src = pj["hbm_bytes_per_launch"], pj.get("source")
+      except Exception:  # pylint: disable=broad-except
+        pass
+    kname = "k_dotg (matrix-core canonical dot)" if B > 8 else "k_dot (vector-ALU canonical dot)"
+    roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": avg_us.value,
+                "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
 
   # ---- CPU baseline: the oracle (a port restating the reference algorithm) on a bounded sample, rank 0, N=1 only
   cpu_baseline = None

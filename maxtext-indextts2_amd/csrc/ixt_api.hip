@@ -428,7 +428,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   float* av = nullptr; int32_t* ai = nullptr;
   int ntiles, slices;
   const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
-  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 64);
+  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 1 << 30);
   if (R < mfma_min_rows || R > mfma_max_rows) {
     const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
     const int rowblocks = (R + rb - 1) / rb;
@@ -466,7 +466,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
     static const int full_units = env_int("IXT_DOT_FULL_UNITS", 1024);
     static const int nrb_env = env_int("IXT_DOT_NRB", 0);
     int nrb = rowblocks >= 3 ? 4 : rowblocks;                      // 16-row blocks sharing one block's loaded weights (1, 2 or 4)
-    if (rowblocks > 4 && (nrb_env == 1 || nrb_env == 2 || nrb_env == 4)) nrb = nrb_env;
+    if (rowblocks > 4) nrb = (nrb_env == 2 || nrb_env == 4) ? nrb_env : 1;   // prefill chunks: more blocks beat weight reuse (measured)
     const int zblocks = (rowblocks + nrb - 1) / nrb;
     bool split = !force_full && !epi_argmax && zblocks == 1 && ntiles < full_units && G > 1;
     if (!use_dotg && rowblocks > 1) split = false;

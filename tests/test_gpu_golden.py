@@ -72,16 +72,18 @@ def test_golden_c2_full_decode(c2_weights):
   assert np.array_equal(out, g["tokens"]), int(np.argmax(np.any(out != g["tokens"], axis=1)))
 
 
-def test_c2_batch8_properties(c2_weights):
-  """Full-size, batch 8: slot 0 carries the golden utterance and must reproduce it whatever the other slots hold;
+@pytest.mark.parametrize("B", [8, 20])
+def test_c2_batch_properties(c2_weights, B):
+  """Full-size, batch 8 (vector-ALU dot kernel) and batch 20 (matrix-core dot kernel, two 16-row blocks per thread block):
+  slot 0 carries the golden utterance and must reproduce it whatever the other slots hold;
   two slots with the same prompt give the same tokens; teacher-forced chunked prefill of prompt+generated tokens
   reproduces the decode path's next token (prefill == decode, tests/model_test.py:115-191 property)."""
   g, w = c2_weights
-  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=8.0, max_prefill_predict_length=256, max_target_length=1280,
-                      pagedattn_tokens_per_page=32, pagedattn_num_pages=8 * 40 + 1, use_chunked_prefill=True, prefill_chunk_size=256)
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=float(B), max_prefill_predict_length=256, max_target_length=1280,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=B * 40 + 1, use_chunked_prefill=True, prefill_chunk_size=256)
   p0 = (g["prompt_tokens"][0], int(g["true_lengths"][0]))
   prompts = [p0] + [H.synth.synth_prompt(cfg.vocab_size, 256, 2000 + s) for s in range(1, 7)] + [p0]
-  steps = 300
+  steps = 300 if B == 8 else 160
   out, eng, params = run_engine(cfg, w, prompts, steps)
   assert np.array_equal(out[:, 0], g["tokens"][:steps + 1, 0])
   assert np.array_equal(out[:, 7], out[:, 0])
