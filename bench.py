@@ -29,6 +29,7 @@ import torch
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_BF16_PEAK = 2.5e15    # FLOP/s dense bf16 (same guide)
+MFMA_F32_PEAK = 157.3e12   # FLOP/s f32-input MFMA (same guide, "Peak FP32 (matrix)")
 
 
 def parse():
@@ -214,6 +215,9 @@ def main():
     for s in range(B):
       eng.release_pages(s)
     achieved = bpl.value / (avg_us.value * 1e-6) / 1e9 if avg_us.value > 0 else 0.0
+    # flops of the same launches: 2 * rows * (weight elements); weight elements ~ (bytes - x - slices) / 2, dominated by the weights
+    w_elems = (nums["body_params"] + nums["unembed_params"]) / (4 * cfg.num_decoder_layers + 1)   # average per dot launch
+    tflops = 2.0 * B * w_elems / (avg_us.value * 1e-6) / 1e12 if avg_us.value > 0 else 0.0
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
@@ -224,14 +228,22 @@ def main():
       except Exception:  # pylint: disable=broad-except
         pass
     kname = "k_dotg (matrix-core canonical dot)" if B > 8 else "k_dot (vector-ALU canonical dot)"
-    roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": avg_us.value,
-                "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
+    hbm_frac, mfma_frac = achieved / (HBM_PEAK / 1e9), tflops / (MFMA_F32_PEAK / 1e12)
+    if B > 8 and mfma_frac > hbm_frac:   # the f32 matrix pipe, not HBM, is the nearer roof once 32+ rows share a weight stream
+      roofline = {"bound": "mfma", "kernel": kname + ", all launches of a decode step", "achieved": tflops, "peak": MFMA_F32_PEAK / 1e12,
+                  "unit": "TFLOP/s", "frac": mfma_frac, "mfma_dtype": "f32 (v_mfma_f32_16x16x4_f32; exact fma chain)", "hbm_GBps": achieved,
+                  "hbm_frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": avg_us.value, "launches": int(n.value),
+                  "algorithmic_bytes_per_launch": bpl.value, "algorithmic_flops_per_launch": 2.0 * B * w_elems}
+    else:
+      roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                  "frac": hbm_frac, "mfma_f32_TFLOPs": tflops, "mfma_f32_frac": mfma_frac, "traffic": traffic, "traffic_source": traffic_src,
+                  "avg_launch_us": avg_us.value, "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
 
   # ---- CPU baseline: the oracle (a port restating the reference algorithm) on a bounded sample, rank 0, N=1 only
   cpu_baseline = None
   if rank == 0 and world == 1 and not args.no_cpu_baseline:
     from oracle import oracle as O
+    O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box's CPU share for one GPU
     host_w = {k: v.detach().contiguous().view(torch.int16).cpu().numpy().view(np.uint16) for k, v in weights.items()}
     ocfg = O.OracleConfig(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, num_query_heads=cfg.num_query_heads, num_kv_heads=cfg.num_kv_heads,
                           head_dim=cfg.head_dim, mlp_dim=cfg.mlp_dim, num_decoder_layers=cfg.num_decoder_layers,

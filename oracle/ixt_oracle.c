@@ -414,6 +414,13 @@ void orc_swiglu(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n) 
     out[i] = f2bf(u * bf2f(b[i]));
   }
 }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+#else
+  (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

@@ -72,6 +72,7 @@ def lib():
     _lib.orc_exp_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
     _lib.orc_swiglu.argtypes = [_u16p, _u16p, _u16p, ctypes.c_int64]
     _lib.orc_num_threads.restype = ctypes.c_int
+    _lib.orc_set_num_threads.argtypes = [ctypes.c_int]
   return _lib
 
 
