@@ -434,14 +434,14 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
     const int rowblocks = (R + rb - 1) / rb;
     const int tiles8 = (N + 511) / 512;
     bool split = !force_full && !epi_argmax && (tiles8 * rowblocks < 224) && G > 1;
-    if (split && (size_t)G * R * N > out_floats) split = false;
+    if (split && (size_t)((G + IXT_SG - 1) / IXT_SG) * R * N > out_floats) split = false;
     if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
     static const int lw_env = env_int("IXT_DOT_LW", 0);
     static const int target = env_int("IXT_DOT_TARGET_BLOCKS", 384);
     int lw = rb == 8 ? 4 : 8;  // 8 rows x 8 columns of accumulators + 16 x 16-B loads do not fit 128 VGPRs (4 waves/SIMD)
     if (lw_env == 8 || lw_env == 4 || lw_env == 2) lw = lw_env;
     else {
-      const long per_tile = (long)rowblocks * (split ? G : 1);
+      const long per_tile = (long)rowblocks * (split ? (G + IXT_SG - 1) / IXT_SG : 1);
       while (lw > 2 && (long)((N + 64 * lw - 1) / (64 * lw)) * per_tile < target) lw >>= 1;
     }
     ntiles = (N + 64 * lw - 1) / (64 * lw);
@@ -449,8 +449,9 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
       av = c->amax_val; ai = c->amax_idx;
     }
-    dim3 grid(ntiles, split ? G : 1, rowblocks);
-    slices = split ? G : 1;
+    const int nsg = (G + IXT_SG - 1) / IXT_SG;
+    dim3 grid(ntiles, split ? nsg : 1, rowblocks);
+    slices = split ? nsg : 1;
     const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
     switch (rb) {
       case 1: launch_dotv_rb<1>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
@@ -462,14 +463,12 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   } else {
     const int rowblocks = (R + 15) / 16;
     ntiles = (N + 127) / 128;
-    static const int use_dotg = env_int("IXT_DOT_G", 1);
     static const int full_units = env_int("IXT_DOT_FULL_UNITS", 1024);
     static const int nrb_env = env_int("IXT_DOT_NRB", 0);
     int nrb = rowblocks >= 3 ? 4 : rowblocks;                      // 16-row blocks sharing one block's loaded weights (1, 2 or 4)
     if (rowblocks > 4) nrb = (nrb_env == 2 || nrb_env == 4) ? nrb_env : 1;   // prefill chunks: more blocks beat weight reuse (measured)
     const int zblocks = (rowblocks + nrb - 1) / nrb;
     bool split = !force_full && !epi_argmax && zblocks == 1 && ntiles < full_units && G > 1;
-    if (!use_dotg && rowblocks > 1) split = false;
     if (split && (size_t)G * R * N > out_floats) split = false;
     if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
     if (epi_argmax) {
@@ -477,10 +476,11 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       av = c->amax_val; ai = c->amax_idx;
     }
     const bool nt = zblocks == 1;  // weights read once per launch
-    slices = split ? G : 1;
+    const int nsg = (G + IXT_SG - 1) / IXT_SG;
+    slices = split ? nsg : 1;
     const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
-    if (use_dotg) {
-      dim3 grid(ntiles, split ? G : 1, zblocks);
+    {
+      dim3 grid(ntiles, split ? nsg : 1, zblocks);
 #define DOTG(S_, E_, B_)                                                                                                                 \
   do {                                                                                                                                   \
     if (nt) hipLaunchKernelGGL((k_dotg<S_, E_, true, B_>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                  \
@@ -492,17 +492,6 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       else DOTG_B(false, 0);
 #undef DOTG_B
 #undef DOTG
-    } else {
-      dim3 grid((ntiles + 3) / 4, split ? G : 1, rowblocks);
-#define DOTM(S_, E_)                                                                                                                     \
-  do {                                                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_dotm<S_, E_, true>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                   \
-    else hipLaunchKernelGGL((k_dotm<S_, E_, false>), grid, dim3(256), 0, st, x, w, K, N, R, out, 1, av, ai, ntiles);                     \
-  } while (0)
-      if (epi_argmax) DOTM(false, 1);
-      else if (split) DOTM(true, 0);
-      else DOTM(false, 0);
-#undef DOTM
     }
     timing_end(c, st, ti);
   }

@@ -9,6 +9,7 @@ typedef uint16_t bf16_t;
 #define IXT_CL 16    // k per fma chain
 #define IXT_NC 8     // chains per group
 #define IXT_GL 128   // k per group (IXT_CL * IXT_NC)
+#define IXT_SG 1     // groups per super-group = the unit of a split-K slice (4 was measured: fewer, fatter blocks starve the f32 matrix pipe at 64 rows)
 #define IXT_SB 4     // logical pages per attention super-block
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -81,153 +81,15 @@ __host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
 }
 
 // =====================================================================================================
-// Canonical DOT on the matrix cores: v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate) is bit-for-bit a k-ordered fmaf
-// chain (CDNA4 guide, "FP32-input MFMA"), so it computes exactly the canonical chain while leaving the VALU nearly idle
-// (one shift/and per weight element to widen bf16), and 16 activation rows cost the same as one.
-//   x layout   bf16, see xidx(): per 16-row block and 64-k half-group the A fragments (A[row = lane&15][k = lane>>4]) of
-//              the 16 instructions are laid out so that each lane reads its 16 values as 32 contiguous bytes
-//   a wave     owns 128 columns: lane (s = lane&15, q = lane>>4) loads 16 B = W[k0 + q][n0 + 8s .. +7]; element j feeds MFMA j
-//              as B[k = q][slot = s], i.e. slot s of accumulator j is column n0 + 8s + j; 8 accumulators x 4 VGPRs
-//   chain      16 k = 4 instructions per accumulator (k ascending), started from 0
-//   group      8 chains added in order into grp (VALU adds); SPLIT: grp -> slice g; !SPLIT: tot += grp over all groups
-//   pipeline   the loads of chain c+PD are issued before chain c is consumed (PD chains = PD KiB per lane-row in flight)
-// grid = (ceil(N/512), nsplit, ceil(R/16)), block 256 = 4 independent waves (no LDS, no barrier).
-// EPI = 1 (only !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75).
+// Canonical DOT (DenseGeneral, linears.py:188-232), two kernels over one x layout and one operation order:
+//   chain       16 consecutive k: a = 0; a = fma(x_k, w_kn, a)
+//   group       8 chains (128 k) added in order from 0
+//   super-group IXT_SG groups (512 k) added in order from 0        <- one f32 "slice" per super-group in split-K launches
+//   total       super-groups added in order from 0
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate) is bit-for-bit a k-ordered fmaf chain (CDNA4 guide, "FP32-input MFMA"),
+// so the matrix-core kernel and the vector-ALU kernel produce identical bits.
 // =====================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-template <bool SPLIT, int EPI, bool NT>
-__global__ __launch_bounds__(256, 2) void k_dotm(const bf16_t* __restrict__ xT, const bf16_t* __restrict__ w, int K, int N, int R,
-                                              float* __restrict__ out, int groups_per_wave, float* __restrict__ amax_val,
-                                              int32_t* __restrict__ amax_idx, int ntiles) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int s = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x * 4 + wave;
-  const int n0 = tile * 128, nl = n0 + s * 8;
-  if (n0 >= N) return;
-  const bool col_ok = nl < N;
-  const int rz = blockIdx.z;
-  const bf16_t* xb = xT + (size_t)rz * K * 16;
-  const int G = K / IXT_GL;
-  int g_begin = 0, g_end = G;
-  if (SPLIT) {
-    g_begin = blockIdx.y * groups_per_wave;
-    g_end = min(G, g_begin + groups_per_wave);
-  }
-  // Two named buffers (A, B), each a QUARTER-GROUP = 2 chains = 32 k: 8 weight loads (16 B) + 1 x load (16 B) per lane, so
-  // a wave keeps 16 KiB of weights in flight.  The loop body (4 chains) is not unrolled further.  (Macros, not lambdas: arrays
-  // captured by reference are not promoted to registers reliably.)
-  u32x4 wA[8], wB[8];
-  u32x4 xA, xB;
-  f32x4 tot[8], grp[8];
-#pragma unroll
-  for (int j = 0; j < 8; ++j) { tot[j] = f32x4(0.0f); grp[j] = f32x4(0.0f); }
-#define IXT_LOAD_Q(WBUF, XBUF, QG)                                                                        \
-  do {                                                                                                    \
-    XBUF = *reinterpret_cast<const u32x4*>(xb + (((size_t)(QG) * 4 + q) * 16 + s) * 8);                  \
-    const bf16_t* wrow_ = w + (size_t)((QG) * 32 + q) * N + nl;                                           \
-    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                                    \
-      const u32x4* pw_ = reinterpret_cast<const u32x4*>(wrow_ + (size_t)(4 * t_) * N);                    \
-      if (!col_ok) WBUF[t_] = u32x4(0);                                                                   \
-      else if constexpr (NT) WBUF[t_] = __builtin_nontemporal_load(pw_);                                  \
-      else WBUF[t_] = *pw_;                                                                               \
-    }                                                                                                     \
-  } while (0)
-#define IXT_CONSUME_Q(WBUF, XBUF)                                                                         \
-  do {                                                                                                    \
-    _Pragma("unroll") for (int c_ = 0; c_ < 2; ++c_) {                                                    \
-      f32x4 acc_[8];                                                                                      \
-      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) acc_[j_] = f32x4(0.0f);                            \
-      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) {                                                  \
-        const int i_ = c_ * 4 + t_;                                                                       \
-        const uint32_t xd_ = XBUF[i_ >> 1];                                                               \
-        const float a_ = (i_ & 1) ? bfhi(xd_) : bflo(xd_);                                                \
-        const u32x4 wv_ = WBUF[i_];                                                                       \
-        acc_[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.x), acc_[0], 0, 0, 0);                \
-        acc_[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.x), acc_[1], 0, 0, 0);                \
-        acc_[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.y), acc_[2], 0, 0, 0);                \
-        acc_[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.y), acc_[3], 0, 0, 0);                \
-        acc_[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.z), acc_[4], 0, 0, 0);                \
-        acc_[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.z), acc_[5], 0, 0, 0);                \
-        acc_[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bflo(wv_.w), acc_[6], 0, 0, 0);                \
-        acc_[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_, bfhi(wv_.w), acc_[7], 0, 0, 0);                \
-        __builtin_amdgcn_sched_barrier(0); /* one k-step at a time: no hoisting of later unpacks */       \
-      }                                                                                                   \
-      _Pragma("unroll") for (int j_ = 0; j_ < 8; ++j_) grp[j_] = grp[j_] + acc_[j_];                      \
-    }                                                                                                     \
-  } while (0)
-  const int qg_begin = g_begin * 4, qg_end = g_end * 4;
-  IXT_LOAD_Q(wA, xA, qg_begin);
-  IXT_LOAD_Q(wB, xB, qg_begin + 1);
-#pragma unroll 1
-  for (int qg = qg_begin; qg < qg_end; qg += 2) {
-    IXT_CONSUME_Q(wA, xA);
-    if (qg + 2 < qg_end) IXT_LOAD_Q(wA, xA, qg + 2);
-    IXT_CONSUME_Q(wB, xB);
-    if (qg + 3 < qg_end) IXT_LOAD_Q(wB, xB, qg + 3);
-    if (((qg + 2) & 3) == 0) {   // a group (four quarter-groups) is complete
-      const int g = qg >> 2;
-      if (SPLIT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = rz * 16 + q * 4 + r;
-          if (row < R && col_ok) {
-            float* dst = out + ((size_t)g * R + row) * N + nl;
-            *reinterpret_cast<float4*>(dst) = make_float4(grp[0][r], grp[1][r], grp[2][r], grp[3][r]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(grp[4][r], grp[5][r], grp[6][r], grp[7][r]);
-          }
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) tot[j] = tot[j] + grp[j];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) grp[j] = f32x4(0.0f);
-    }
-  }
-  if (!SPLIT && EPI == 0) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rz * 16 + q * 4 + r;
-      if (row < R && col_ok) {
-        float* dst = out + (size_t)row * N + nl;
-        *reinterpret_cast<float4*>(dst) = make_float4(tot[0][r], tot[1][r], tot[2][r], tot[3][r]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[4][r], tot[5][r], tot[6][r], tot[7][r]);
-      }
-    }
-  }
-  if (!SPLIT && EPI == 1) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = rz * 16 + q * 4 + r;
-      float v[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j] = rbf(tot[j][r]);
-      if (row < R && col_ok && out != nullptr) {
-        float* dst = out + (size_t)row * N + nl;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      }
-      float best = -INFINITY;
-      int bidx = 0x7fffffff;
-      if (col_ok) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (v[j] > best) { best = v[j]; bidx = nl + j; }   // ascending j: first index wins ties
-      }
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {   // lanes with the same q hold the same rows
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-      }
-      if (s == 0 && row < R) {
-        amax_val[(size_t)row * ntiles + tile] = best;
-        amax_idx[(size_t)row * ntiles + tile] = bidx;
-      }
-    }
-  }
-}
 
 // =====================================================================================================
 // The same canonical DOT on the vector ALU (v_pk_fma_f32), for <= 8 activation rows per block (decode): at 8 rows the f32
@@ -259,14 +121,14 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, co
   const int r0 = blockIdx.z * RB;
   const int G = K / IXT_GL;
   int g_begin = 0, g_end = G;
-  if (SPLIT) {
-    g_begin = blockIdx.y * groups_per_block;
-    g_end = min(G, g_begin + groups_per_block);
+  if (SPLIT) {   // one super-group per block
+    g_begin = blockIdx.y * IXT_SG;
+    g_end = min(G, g_begin + IXT_SG);
   }
   const int ocol = tid % TW, opart = tid / TW;
-  float tot[RB];
+  float tot[RB], sgs[RB];   // total over super-groups, running super-group sum
 #pragma unroll
-  for (int r = 0; r < RB; ++r) tot[r] = 0.0f;
+  for (int r = 0; r < RB; ++r) { tot[r] = 0.0f; sgs[r] = 0.0f; }
 
   for (int g = g_begin; g < g_end; ++g) {
     const int kbase = g * IXT_GL + wave * IXT_CL;
@@ -339,10 +201,14 @@ __global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, co
 #pragma unroll
           for (int c = 0; c < IXT_NC; ++c) s = s + red[(c * RH + r) * TW + ocol];
           const int row = r0 + hh * RH + r;
-          if (SPLIT) {
-            if (row < R && n0 + ocol < N) out[((size_t)g * R + row) * N + n0 + ocol] = s;
-          } else {
-            tot[hh * RH + r] = tot[hh * RH + r] + s;
+          sgs[hh * RH + r] = sgs[hh * RH + r] + s;
+          if (((g + 1) % IXT_SG) == 0 || g + 1 == g_end) {   // super-group complete
+            if (SPLIT) {
+              if (row < R && n0 + ocol < N) out[((size_t)blockIdx.y * R + row) * N + n0 + ocol] = sgs[hh * RH + r];
+            } else {
+              tot[hh * RH + r] = tot[hh * RH + r] + sgs[hh * RH + r];
+            }
+            sgs[hh * RH + r] = 0.0f;
           }
         }
       }
@@ -414,14 +280,14 @@ __global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, 
   const int rz0 = blockIdx.z * NRB;                       // first 16-row block of this thread block
   const int G = K / IXT_GL;
   int g_begin = 0, g_end = G;
-  if (SPLIT) { g_begin = blockIdx.y; g_end = g_begin + 1; }
+  if (SPLIT) { g_begin = blockIdx.y * IXT_SG; g_end = min(G, g_begin + IXT_SG); }   // one super-group per block
   // reducer role
   const int orow = tid >> 4, ocol = (tid & 15) * 8;
-  float tot[NRB][8];
+  float tot[NRB][8], sgs[NRB][8];   // total over super-groups, running super-group sum
 #pragma unroll
   for (int b = 0; b < NRB; ++b)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) tot[b][j] = 0.0f;
+    for (int j = 0; j < 8; ++j) { tot[b][j] = 0.0f; sgs[b][j] = 0.0f; }
 
   u32x4 wq[8];
   u32x4 xq[NRB];
@@ -493,15 +359,21 @@ __global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, 
           sum[4] = sum[4] + a1.x; sum[5] = sum[5] + a1.y; sum[6] = sum[6] + a1.z; sum[7] = sum[7] + a1.w;
         }
         const int row = (rz0 + b) * 16 + orow;
-        if (SPLIT) {
-          if (row < R && n0 + ocol < N) {
-            float* dst = out + ((size_t)g * R + row) * N + n0 + ocol;
-            *reinterpret_cast<float4*>(dst) = make_float4(sum[0], sum[1], sum[2], sum[3]);
-            *reinterpret_cast<float4*>(dst + 4) = make_float4(sum[4], sum[5], sum[6], sum[7]);
-          }
-        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) tot[b][j] = tot[b][j] + sum[j];
+        for (int j = 0; j < 8; ++j) sgs[b][j] = sgs[b][j] + sum[j];
+        if (((g + 1) % IXT_SG) == 0 || g + 1 == g_end) {   // super-group complete
+          if (SPLIT) {
+            if (row < R && n0 + ocol < N) {
+              float* dst = out + ((size_t)blockIdx.y * R + row) * N + n0 + ocol;
+              *reinterpret_cast<float4*>(dst) = make_float4(sgs[b][0], sgs[b][1], sgs[b][2], sgs[b][3]);
+              *reinterpret_cast<float4*>(dst + 4) = make_float4(sgs[b][4], sgs[b][5], sgs[b][6], sgs[b][7]);
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) tot[b][j] = tot[b][j] + sgs[b][j];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) sgs[b][j] = 0.0f;
         }
       }
     }

@@ -40,6 +40,7 @@
 #define ORC_CL 16   /* chain length (k per fma chain)          */
 #define ORC_NC 8    /* chains per group -> group = 128 k       */
 #define ORC_GL (ORC_CL * ORC_NC)
+#define ORC_SG 1    /* groups per super-group (1: every 128-k group is its own split-K slice) */
 #define ORC_SB 4    /* pages per attention super-block         */
 
 typedef struct orc_model {
@@ -165,9 +166,10 @@ void orc_rope(uint16_t* v, int nh, int hd, const uint16_t* sn, const uint16_t* c
 /* ---------------------------------------------------------------- canonical DOT */
 /* out[r][n] (f32, unrounded) = DOT(x[r][:], W[:, n]); x bf16 [R][K] (row stride ldx),
  * W bf16 [K][N].  K % 128 == 0.
- *   chain  c: a = 0; for k in [16c,16c+16): a = fma(x_k, w_kn, a)
- *   group  g: s = 0; for c in [8g,8g+8):   s = s + chain(c)
- *   total   : t = 0; for g:                t = t + group(g)              */
+ *   chain       c: a = 0; for k in [16c,16c+16): a = fma(x_k, w_kn, a)
+ *   group       g: s = 0; for c in [8g,8g+8):   s = s + chain(c)
+ *   super-group u: v = 0; for g in [4u,4u+4):   v = v + group(g)      (the last one may be short)
+ *   total        : t = 0; for u:                t = t + super-group(u)              */
 #define ORC_NB 512
 void orc_dot_rows(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, int N, float* out, int ldo) {
   int nblocks = (N + ORC_NB - 1) / ORC_NB;
@@ -178,11 +180,12 @@ void orc_dot_rows(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, i
     float* ch = (float*)malloc(sizeof(float) * ORC_NB);
     float* grp = (float*)malloc(sizeof(float) * (size_t)R * ORC_NB);
     float* tot = (float*)malloc(sizeof(float) * (size_t)R * ORC_NB);
+    float* sgs = (float*)malloc(sizeof(float) * (size_t)R * ORC_NB);
 #pragma omp for schedule(dynamic, 1)
     for (int nb = 0; nb < nblocks; ++nb) {
       int n0 = nb * ORC_NB;
       int nn = N - n0 < ORC_NB ? N - n0 : ORC_NB;
-      for (size_t i = 0; i < (size_t)R * ORC_NB; ++i) tot[i] = 0.0f;
+      for (size_t i = 0; i < (size_t)R * ORC_NB; ++i) { tot[i] = 0.0f; sgs[i] = 0.0f; }
       for (int g = 0; g < ngroups; ++g) {
         for (size_t i = 0; i < (size_t)R * ORC_NB; ++i) grp[i] = 0.0f;
         for (int c = 0; c < ORC_NC; ++c) {
@@ -204,10 +207,14 @@ void orc_dot_rows(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, i
             for (int n = 0; n < nn; ++n) gr[n] = gr[n] + ch[n];
           }
         }
+        const int sg_done = ((g + 1) % ORC_SG) == 0 || g + 1 == ngroups;
         for (int r = 0; r < R; ++r) {
           float* gr = grp + (size_t)r * ORC_NB;
+          float* sr = sgs + (size_t)r * ORC_NB;
           float* tr = tot + (size_t)r * ORC_NB;
-          for (int n = 0; n < nn; ++n) tr[n] = tr[n] + gr[n];
+          for (int n = 0; n < nn; ++n) sr[n] = sr[n] + gr[n];
+          if (sg_done)
+            for (int n = 0; n < nn; ++n) { tr[n] = tr[n] + sr[n]; sr[n] = 0.0f; }
         }
       }
       for (int r = 0; r < R; ++r) {
@@ -216,7 +223,7 @@ void orc_dot_rows(const uint16_t* x, int ldx, int R, const uint16_t* W, int K, i
         for (int n = 0; n < nn; ++n) o[n] = tr[n];
       }
     }
-    free(wf); free(ch); free(grp); free(tot);
+    free(wf); free(ch); free(grp); free(tot); free(sgs);
   }
 }
 
