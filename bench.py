@@ -227,17 +227,12 @@ def main():
           traffic, traffic_src = pj["hbm_bytes_per_launch"], pj.get("source")
       except Exception:  # pylint: disable=broad-except
         pass
-    kname = "k_dotg (matrix-core canonical dot)" if B > 8 else "k_dot (vector-ALU canonical dot)"
-    hbm_frac, mfma_frac = achieved / (HBM_PEAK / 1e9), tflops / (MFMA_F32_PEAK / 1e12)
-    if B > 8 and mfma_frac > hbm_frac:   # the f32 matrix pipe, not HBM, is the nearer roof once 32+ rows share a weight stream
-      roofline = {"bound": "mfma", "kernel": kname + ", all launches of a decode step", "achieved": tflops, "peak": MFMA_F32_PEAK / 1e12,
-                  "unit": "TFLOP/s", "frac": mfma_frac, "mfma_dtype": "f32 (v_mfma_f32_16x16x4_f32; exact fma chain)", "hbm_GBps": achieved,
-                  "hbm_frac": hbm_frac, "traffic": traffic, "traffic_source": traffic_src, "avg_launch_us": avg_us.value, "launches": int(n.value),
-                  "algorithmic_bytes_per_launch": bpl.value, "algorithmic_flops_per_launch": 2.0 * B * w_elems}
-    else:
-      roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                  "frac": hbm_frac, "mfma_f32_TFLOPs": tflops, "mfma_f32_frac": mfma_frac, "traffic": traffic, "traffic_source": traffic_src,
-                  "avg_launch_us": avg_us.value, "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
+    kname = "k_dotb (canonical dot on v_mfma_f32_16x16x32_bf16)"
+    hbm_frac, mfma_frac = achieved / (HBM_PEAK / 1e9), tflops / (MFMA_BF16_PEAK / 1e12)
+    # bf16 matrix cores: 2.5 PFLOP/s dense; at <= 64 rows per weight stream the dot is bound by the weight bytes, not the matrix pipe
+    roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": hbm_frac, "mfma_bf16_TFLOPs": tflops, "mfma_bf16_frac": mfma_frac, "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": avg_us.value, "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
 
   # ---- CPU baseline: the oracle (a port restating the reference algorithm) on a bounded sample, rank 0, N=1 only
   cpu_baseline = None
@@ -279,7 +274,7 @@ def main():
     out = {
         "metric": "audio-tokens/sec (prefill+decode) @ 1B IndexTTS2", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 storage, f32 accumulate", "data": "synthetic",
+        "dtype": "bf16 (bf16 matrix-core dots, f32 accumulate; f32 fma chains in attention/norms)", "data": "synthetic",
         "config": {"workload": f"C2 {args.model}: {P}-token prefill -> {args.decode_steps} greedy audio-token decode steps, {B} utterances/GPU, paged KV (32 tok/page)",
                    "utterances_per_gpu": B, "prefill_len": P, "decode_steps": args.decode_steps, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
         "per_gpu_tokens_per_s": value / world,

@@ -63,8 +63,10 @@ struct ixt_ctx {
   float *part = nullptr, *scores = nullptr, *pvpart = nullptr, *amax_val = nullptr;
   int32_t* amax_idx = nullptr;
   size_t amax_cap = 0;
-  bf16_t* xt_op = nullptr;  // op-level entry points: k-major copy of the caller's row-major x
+  bf16_t* xt_op = nullptr;  // op-level entry points: the caller's row-major x in the dot kernel's x layout
   size_t xt_cap = 0;
+  bf16_t* wt_op = nullptr;  // ixt_op_dot: the caller's row-major kernel in the tiled weight layout (grown on demand)
+  size_t wt_cap = 0;
   size_t part_floats = 0;
   int32_t *row_slot = nullptr, *row_pos = nullptr, *row_active = nullptr, *row_tok = nullptr, *new_tok = nullptr;
   AttnGeom geom{};
@@ -117,14 +119,14 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
   const ixt_config& c = *cfg;
   if (c.head_dim != 64 && c.head_dim != 128) return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 or 128 built)", c.head_dim);
-  if (c.emb_dim % IXT_GL || c.mlp_dim % IXT_GL || (c.num_query_heads * c.head_dim) % IXT_GL)
-    return set_err(IXT_ERR_UNSUPPORTED, "emb_dim, mlp_dim and num_query_heads*head_dim must be multiples of %d", IXT_GL);
+  if (c.emb_dim % IXT_KALIGN || c.mlp_dim % IXT_KALIGN || (c.num_query_heads * c.head_dim) % IXT_KALIGN)
+    return set_err(IXT_ERR_UNSUPPORTED, "emb_dim, mlp_dim and num_query_heads*head_dim must be multiples of %d", IXT_KALIGN);
   if (c.num_kv_heads <= 0 || c.num_query_heads % c.num_kv_heads) return set_err(IXT_ERR_INVALID, "num_query_heads %% num_kv_heads != 0");
   const int gq = c.num_query_heads / c.num_kv_heads;
   if (gq != 1 && gq != 2 && gq != 4) return set_err(IXT_ERR_UNSUPPORTED, "query heads per kv head = %d (1, 2, 4 built)", gq);
   if (!is_pow2(c.pagedattn_tokens_per_page) || c.pagedattn_tokens_per_page < 8 || c.pagedattn_tokens_per_page > 64)
     return set_err(IXT_ERR_UNSUPPORTED, "pagedattn_tokens_per_page must be a power of two in [8, 64]");
-  if (c.vocab_size % 8) return set_err(IXT_ERR_UNSUPPORTED, "vocab_size must be a multiple of 8");
+  if (c.vocab_size % 16) return set_err(IXT_ERR_UNSUPPORTED, "vocab_size must be a multiple of 16");
   // page_manager.py:450-473
   if (c.pagedattn_max_pages_per_group <= 0) return set_err(IXT_ERR_INVALID, "`pagedattn_max_pages_per_group` must be positive.");
   if (c.pagedattn_max_pages_per_group < (c.max_target_length + c.pagedattn_tokens_per_page - 1) / c.pagedattn_tokens_per_page)
@@ -192,12 +194,12 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   A(dmalloc(x, &x->ao, Rp * x->QN));
   A(dmalloc(x, &x->hact, Rp * F));
   {
-    // partial slices: SPLIT launches write K/128 slices of [R<=8][N]; FULL launches one slice of [R][N]
+    // partial slices: SPLIT launches write ceil(K/512) slices of [R][N]; FULL launches one slice of [R][N]
     size_t nmax = (size_t)x->NQKV > (size_t)2 * F ? x->NQKV : (size_t)2 * F;
     if ((size_t)E > nmax) nmax = E;
     size_t full = (size_t)R * nmax;
     size_t gmaxn = 0;
-    auto upd = [&](int K, int N) { size_t v = (size_t)(K / IXT_GL) * N; if (v > gmaxn) gmaxn = v; };
+    auto upd = [&](int K, int N) { size_t v = (size_t)((K + IXT_CHAIN - 1) / IXT_CHAIN) * N; if (v > gmaxn) gmaxn = v; };
     upd(E, x->NQKV); upd(x->QN, E); upd(E, 2 * F); upd(F, E);
     size_t split = gmaxn * (size_t)R;  // generous: any R may use SPLIT
     x->part_floats = full > split ? full : split;
@@ -205,7 +207,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   }
   A(dmalloc(x, &x->scores, (size_t)R * x->Q * x->Tmax));
   A(dmalloc(x, &x->pvpart, (size_t)R * x->Q * x->nsb_max * x->D));
-  x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 127) / 128);
+  x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 15) / 16);
   A(dmalloc(x, &x->amax_val, x->amax_cap));
   A(dmalloc(x, &x->amax_idx, x->amax_cap));
   {
@@ -234,6 +236,7 @@ extern "C" int ixt_destroy(ixt_ctx* c) {
   for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
   for (auto& t : c->tpairs) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (void* p : c->allocs) (void)hipFree(p);
+  if (c->wt_op) (void)hipFree(c->wt_op);
   delete c;
   return IXT_OK;
 }
@@ -244,6 +247,17 @@ static int copy_param(const void* src, int dtype, bf16_t* dst, int64_t rows, int
   const int blocks = (int)((n + 255) / 256);
   if (dtype == IXT_BF16) hipLaunchKernelGGL((k_copy_convert<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, rows, cols, ldd);
   else if (dtype == IXT_F32) hipLaunchKernelGGL((k_copy_convert<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, rows, cols, ldd);
+  else return set_err(IXT_ERR_INVALID, "dtype %d", dtype);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+// a [K][ncols] kernel of the reference (row-major, linears.py:205-217) -> columns n_off.. of the tiled matrix `dst` (widx)
+static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols, int n_off, hipStream_t st) {
+  if (ncols % 16 || n_off % 16 || K % IXT_MK) return set_err(IXT_ERR_UNSUPPORTED, "kernel %d x %d: columns %% 16 or rows %% 32", K, ncols);
+  const int64_t n = (int64_t)K * ncols;
+  const unsigned blocks = (unsigned)((n + 255) / 256);
+  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_tile_w<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, K, ncols, n_off);
+  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_tile_w<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, K, ncols, n_off);
   else return set_err(IXT_ERR_INVALID, "dtype %d", dtype);
   LAUNCHCHK();
   return IXT_OK;
@@ -268,7 +282,7 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
     TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, c->final_norm, 1, E, E, st)); c->loaded[c->L] |= 2; return IXT_OK;
   }
   if (p == "decoder/logits_dense/kernel") {
-    TRY(expect((int64_t)E * V)); TRY(copy_param(dev_ptr, dtype, c->logits_w, E, V, V, st)); c->loaded[c->L] |= 4; return IXT_OK;
+    TRY(expect((int64_t)E * V)); TRY(tile_param(dev_ptr, dtype, c->logits_w, E, V, 0, st)); c->loaded[c->L] |= 4; return IXT_OK;
   }
   int li = -1, consumed = 0;
   if (sscanf(p.c_str(), "decoder/layers_%d/%n", &li, &consumed) < 1 || li < 0 || li >= c->L || consumed == 0)
@@ -277,14 +291,14 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
   LayerW& w = c->layers[li];
   uint32_t& m = c->loaded[li];
   if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
-  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(copy_param(dev_ptr, dtype, w.wqkv, E, c->QN, c->NQKV, st)); m |= 1u << W_Q; }
-  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(copy_param(dev_ptr, dtype, w.wqkv + c->QN, E, c->KN, c->NQKV, st)); m |= 1u << W_K; }
-  else if (rest == "self_attention/value/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(copy_param(dev_ptr, dtype, w.wqkv + c->QN + c->KN, E, c->KN, c->NQKV, st)); m |= 1u << W_V; }
-  else if (rest == "self_attention/out/kernel") { TRY(expect((int64_t)c->QN * E)); TRY(copy_param(dev_ptr, dtype, w.wo, c->QN, E, E, st)); m |= 1u << W_O; }
+  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st)); m |= 1u << W_Q; }
+  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st)); m |= 1u << W_K; }
+  else if (rest == "self_attention/value/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN + c->KN, st)); m |= 1u << W_V; }
+  else if (rest == "self_attention/out/kernel") { TRY(expect((int64_t)c->QN * E)); TRY(tile_param(dev_ptr, dtype, w.wo, c->QN, E, 0, st)); m |= 1u << W_O; }
   else if (rest == "mlp/mlp_layer_norm/scale" || rest == "post_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln2, 1, E, E, st)); m |= 1u << W_LN2; }
-  else if (rest == "mlp/wi_0/kernel") { TRY(expect((int64_t)E * F)); TRY(copy_param(dev_ptr, dtype, w.wi, E, F, 2 * F, st)); m |= 1u << W_WI0; }
-  else if (rest == "mlp/wi_1/kernel") { TRY(expect((int64_t)E * F)); TRY(copy_param(dev_ptr, dtype, w.wi + F, E, F, 2 * F, st)); m |= 1u << W_WI1; }
-  else if (rest == "mlp/wo/kernel") { TRY(expect((int64_t)F * E)); TRY(copy_param(dev_ptr, dtype, w.wout, F, E, E, st)); m |= 1u << W_WOUT; }
+  else if (rest == "mlp/wi_0/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, 0, st)); m |= 1u << W_WI0; }
+  else if (rest == "mlp/wi_1/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, F, st)); m |= 1u << W_WI1; }
+  else if (rest == "mlp/wo/kernel") { TRY(expect((int64_t)F * E)); TRY(tile_param(dev_ptr, dtype, w.wout, F, E, 0, st)); m |= 1u << W_WOUT; }
   else return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
   return IXT_OK;
 }
@@ -394,111 +408,62 @@ static int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
-template <int RB, int LW>
-static void launch_dotv_v(const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, float* av, int32_t* ai, dim3 grid, bool split, bool nt,
-                          bool epi, hipStream_t st) {
-#define DOT_GO(S_, E_)                                                                                                      \
-  do {                                                                                                                      \
-    if (nt) hipLaunchKernelGGL((k_dot<RB, LW, S_, E_, true>), grid, dim3(512), 0, st, x, w, K, N, R, out, 1, av, ai);       \
-    else hipLaunchKernelGGL((k_dot<RB, LW, S_, E_, false>), grid, dim3(512), 0, st, x, w, K, N, R, out, 1, av, ai);         \
-  } while (0)
-  if (epi) DOT_GO(false, 1);
-  else if (split) DOT_GO(true, 0);
-  else DOT_GO(false, 0);
-#undef DOT_GO
-}
-template <int RB>
-static void launch_dotv_rb(const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, float* av, int32_t* ai, dim3 grid, int lw, bool split,
-                           bool nt, bool epi, hipStream_t st) {
-  if (lw == 8) launch_dotv_v<RB, 8>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
-  else if (lw == 4) launch_dotv_v<RB, 4>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
-  else launch_dotv_v<RB, 2>(x, w, K, N, R, out, av, ai, grid, split, nt, epi, st);
-}
-
-// x: bf16 in the dot x layout (xidx).  out: f32 [slices][R][N]; force_full: one slice (all groups added inside the block/wave).
-// epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store logits; (max,idx) pairs -> c->amax_*).
-// R <= 8: vector-ALU kernel (8 waves per group, all loads of a block in flight at once); more rows: matrix-core kernel
-// (16 rows per wave for the price of one).
+// x: bf16 in the dot x layout (xidx); w: bf16 in the tiled weight layout (widx).  out: f32 [slices][R][N]; force_full: one
+// slice (all chains added inside the wave).  epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store
+// logits; (max,idx) pairs -> c->amax_*).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per wave).
 static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
                       bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false) {
-  if (K % IXT_GL || N % 8) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 128 or N %% 8");
+  if (K % IXT_MK || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 32 or N %% 16");
   if (out == nullptr && !epi_argmax) return set_err(IXT_ERR_INVALID, "dot: null output");
-  const int G = K / IXT_GL;
-  static const int mfma_min_rows = env_int("IXT_DOT_MFMA_MIN_ROWS", 9);
+  const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
+  const int ntile = N / 16;
+  const int rowblocks = (R + 15) / 16;
+  static const int nrb_env = env_int("IXT_DOT_NRB", 0);
+  static const int ts_env = env_int("IXT_DOT_EPI_TS", 4);
+  static const int wpb_env = env_int("IXT_DOT_WPB", 0);
+  int nrb = rowblocks >= 3 ? 4 : rowblocks;
+  if (nrb_env == 1 || nrb_env == 2 || nrb_env == 4) nrb = nrb_env;
+  const int zblocks = (rowblocks + nrb - 1) / nrb;
+  bool split = !force_full && !epi_argmax && chains > 1 && zblocks == 1;
+  if (split && (size_t)chains * R * N > out_floats) split = false;
+  if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+  const int TS = epi_argmax ? (ts_env > 0 ? ts_env : 1) : 1;
+  const int nwaves = (ntile + TS - 1) / TS;
   float* av = nullptr; int32_t* ai = nullptr;
-  int ntiles, slices;
-  const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
-  static const int mfma_max_rows = env_int("IXT_DOT_MFMA_MAX_ROWS", 1 << 30);
-  if (R < mfma_min_rows || R > mfma_max_rows) {
-    const int rb = R <= 1 ? 1 : R <= 2 ? 2 : R <= 4 ? 4 : 8;
-    const int rowblocks = (R + rb - 1) / rb;
-    const int tiles8 = (N + 511) / 512;
-    bool split = !force_full && !epi_argmax && (tiles8 * rowblocks < 224) && G > 1;
-    if (split && (size_t)((G + IXT_SG - 1) / IXT_SG) * R * N > out_floats) split = false;
-    if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
-    static const int lw_env = env_int("IXT_DOT_LW", 0);
-    static const int target = env_int("IXT_DOT_TARGET_BLOCKS", 384);
-    int lw = rb == 8 ? 4 : 8;  // 8 rows x 8 columns of accumulators + 16 x 16-B loads do not fit 128 VGPRs (4 waves/SIMD)
-    if (lw_env == 8 || lw_env == 4 || lw_env == 2) lw = lw_env;
-    else {
-      const long per_tile = (long)rowblocks * (split ? (G + IXT_SG - 1) / IXT_SG : 1);
-      while (lw > 2 && (long)((N + 64 * lw - 1) / (64 * lw)) * per_tile < target) lw >>= 1;
-    }
-    ntiles = (N + 64 * lw - 1) / (64 * lw);
-    if (epi_argmax) {
-      if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
-      av = c->amax_val; ai = c->amax_idx;
-    }
-    const int nsg = (G + IXT_SG - 1) / IXT_SG;
-    dim3 grid(ntiles, split ? nsg : 1, rowblocks);
-    slices = split ? nsg : 1;
-    const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
-    switch (rb) {
-      case 1: launch_dotv_rb<1>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
-      case 2: launch_dotv_rb<2>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
-      case 4: launch_dotv_rb<4>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
-      default: launch_dotv_rb<8>(x, w, K, N, R, out, av, ai, grid, lw, split, rowblocks == 1, epi_argmax, st); break;
-    }
-    timing_end(c, st, ti);
-  } else {
-    const int rowblocks = (R + 15) / 16;
-    ntiles = (N + 127) / 128;
-    static const int full_units = env_int("IXT_DOT_FULL_UNITS", 1024);
-    static const int nrb_env = env_int("IXT_DOT_NRB", 0);
-    int nrb = rowblocks >= 3 ? 4 : rowblocks;                      // 16-row blocks sharing one block's loaded weights (1, 2 or 4)
-    if (rowblocks > 4) nrb = (nrb_env == 2 || nrb_env == 4) ? nrb_env : 1;   // prefill chunks: more blocks beat weight reuse (measured)
-    const int zblocks = (rowblocks + nrb - 1) / nrb;
-    bool split = !force_full && !epi_argmax && zblocks == 1 && ntiles < full_units && G > 1;
-    if (split && (size_t)G * R * N > out_floats) split = false;
-    if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
-    if (epi_argmax) {
-      if ((size_t)R * ntiles > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
-      av = c->amax_val; ai = c->amax_idx;
-    }
-    const bool nt = zblocks == 1;  // weights read once per launch
-    const int nsg = (G + IXT_SG - 1) / IXT_SG;
-    slices = split ? nsg : 1;
-    const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
-    {
-      dim3 grid(ntiles, split ? nsg : 1, zblocks);
-#define DOTG(S_, E_, B_)                                                                                                                 \
-  do {                                                                                                                                   \
-    if (nt) hipLaunchKernelGGL((k_dotg<S_, E_, true, B_>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                  \
-    else hipLaunchKernelGGL((k_dotg<S_, E_, false, B_>), grid, dim3(256), 0, st, x, w, K, N, R, out, av, ai, ntiles);                    \
-  } while (0)
-#define DOTG_B(S_, E_) do { if (nrb == 4) DOTG(S_, E_, 4); else if (nrb == 2) DOTG(S_, E_, 2); else DOTG(S_, E_, 1); } while (0)
-      if (epi_argmax) DOTG_B(false, 1);
-      else if (split) DOTG_B(true, 0);
-      else DOTG_B(false, 0);
-#undef DOTG_B
-#undef DOTG
-    }
-    timing_end(c, st, ti);
+  if (epi_argmax) {
+    if ((size_t)R * nwaves > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+    av = c->amax_val; ai = c->amax_idx;
   }
+  const bool nt = zblocks == 1;  // weights read once per launch
+  const int slices = split ? chains : 1;
+  // waves per block: 4 share one LDS copy of the activations; 2 when that would leave CUs without a block
+  int wpb = (split || (long)((nwaves + 3) / 4) * zblocks >= 256) ? 4 : 2;   // (split-K blocks are always 4 waves: measured faster, and the kernel relies on it)
+  if (!split && (wpb_env == 1 || wpb_env == 2 || wpb_env == 4)) wpb = wpb_env;
+  const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
+  const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
+  {
+    dim3 grid((nwaves + wpb - 1) / wpb, split ? chains : 1, zblocks);
+    const dim3 block(64 * wpb);
+    const size_t lds = (size_t)nrb * 16 * 1024;
+    const u32x4* xp = reinterpret_cast<const u32x4*>(x);
+    const u32x4* wp = reinterpret_cast<const u32x4*>(w);
+#define DOTB(B_, S_, E_)                                                                                                        \
+  do {                                                                                                                          \
+    if (nt) hipLaunchKernelGGL((k_dotb<B_, S_, E_, true>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS);     \
+    else hipLaunchKernelGGL((k_dotb<B_, S_, E_, false>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS);       \
+  } while (0)
+#define DOTB_B(S_, E_) do { if (nrb == 4) DOTB(4, S_, E_); else if (nrb == 2) DOTB(2, S_, E_); else DOTB(1, S_, E_); } while (0)
+    if (epi_argmax) DOTB_B(false, 1);
+    else if (split) DOTB_B(true, 0);
+    else DOTB_B(false, 0);
+#undef DOTB_B
+#undef DOTB
+  }
+  timing_end(c, st, ti);
   LAUNCHCHK();
   res->slices = slices;
   res->slice_stride = (size_t)R * N;
-  res->ntiles = ntiles;
+  res->ntiles = nwaves;
   return IXT_OK;
 }
 
@@ -767,9 +732,18 @@ static int transpose_rows(ixt_ctx* c, const bf16_t* x, int R, int K, hipStream_t
 extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream) {
   if (!c || !x || !w || !out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
+  if (K % IXT_MK || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 32 or N %% 16");
+  if ((size_t)((K + IXT_CHAIN - 1) / IXT_CHAIN) * R * N > c->part_floats && (size_t)R * N > c->part_floats)
+    return set_err(IXT_ERR_INVALID, "op: %d x %d outputs exceed the scratch of this ctx", R, N);
   TRY(transpose_rows(c, x, R, K, st));
+  if ((size_t)K * N > c->wt_cap) {
+    if (c->wt_op) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->wt_op)); c->wt_op = nullptr; c->wt_cap = 0; }
+    HIPCHK(hipMalloc((void**)&c->wt_op, (size_t)K * N * sizeof(bf16_t)));
+    c->wt_cap = (size_t)K * N;
+  }
+  TRY(tile_param(w, IXT_BF16, c->wt_op, K, N, 0, st));
   DotResult dr;
-  TRY(launch_dot(c, c->xt_op, w, K, N, R, c->part, c->part_floats, false, st, &dr));
+  TRY(launch_dot(c, c->xt_op, c->wt_op, K, N, R, c->part, c->part_floats, false, st, &dr));
   const size_t n = (size_t)R * N;
   hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
   LAUNCHCHK();

@@ -1,4 +1,4 @@
-// ixt_device.h -- scalar numerics shared by every kernel ("IXT-F32-v1").
+// ixt_device.h -- scalar numerics shared by every kernel ("IXT-MFMA-v2").
 // Compiled with -ffp-contract=off: a*b+c never fuses; every fused multiply-add is an explicit fmaf.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -6,10 +6,9 @@
 
 typedef uint16_t bf16_t;
 
-#define IXT_CL 16    // k per fma chain
-#define IXT_NC 8     // chains per group
-#define IXT_GL 128   // k per group (IXT_CL * IXT_NC)
-#define IXT_SG 1     // groups per super-group = the unit of a split-K slice (4 was measured: fewer, fatter blocks starve the f32 matrix pipe at 64 rows)
+#define IXT_MK 32      // k per matrix instruction (v_mfma_f32_16x16x32_bf16)
+#define IXT_CHAIN 512  // k per accumulator chain of the canonical dot = the unit of a split-K slice
+#define IXT_KALIGN 128 // feature dimensions must be multiples of this
 #define IXT_SB 4     // logical pages per attention super-block
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }

@@ -1,34 +1,13 @@
 // ixt_kernels.h -- gfx950 kernels of the hot path.  Wave = 64 lanes everywhere.
 //
 // HBM layouts:
-//   weights      bf16 row-major [K][N] (N contiguous): a wave reads 64 lanes x 16 B = 1 KiB of one k-row
+//   weights      bf16, MFMA-fragment tiled [N/16][K/32][(k%32)/8][n%16][k%8]: a wave reads 1 KiB per k-step, contiguous along k
 //   K pages      bf16 [layer][page][kv_head][hd/8][tok][8]   (token-minor inside a d-chunk: a wave's
 //                score load is tokens_per_page x 16 B contiguous per page)
 //   V pages      bf16 [layer][page][kv_head][tok][hd]        (a wave's PV load is 256 B contiguous per page)
 //   partials     f32  [slice][row][N]
 #pragma once
 #include "ixt_device.h"
-
-// =====================================================================================================
-// Canonical DOT (DenseGeneral, linears.py:188-232).
-//   grid  = (ceil(N/512), nsplit, ceil(R/RB));  block = 512 threads = 8 waves.
-//   wave w of the block owns chain w of each 128-k group: 16 k-rows x 512 columns, one 16 B load per lane
-//   per k-row, 8 columns x RB rows of f32 accumulators per lane.  The 8 chain results of a group are added
-//   in chain order through LDS (thread t owns column t).  SPLIT: every group sum is written to its own
-//   partial slice (consumer adds slices in order).  !SPLIT: the block walks all groups and adds the group
-//   sums in order itself (one slice).
-// =====================================================================================================
-struct DotArgs {
-  const bf16_t* x;   // [R][K], row stride ldx
-  int ldx;
-  const bf16_t* w;   // [K][N]
-  int K, N, R;
-  float* out;        // [slices][R][N]
-  int groups_per_block;  // SPLIT: groups handled by one block (blockIdx.y picks the range)
-  float* amax_val = nullptr;     // EPI 1: [R][ntiles]
-  int32_t* amax_idx = nullptr;   // EPI 1: [R][ntiles]
-  int xmode = 0;
-};
 
 // Sum of partial slices in slice order, with the loads of up to U slices issued together (the adds stay
 // sequential; padding with +0.0f is exact because a running sum that started at +0.0f is never -0.0f).
@@ -57,368 +36,184 @@ __device__ __forceinline__ float2 sum_slices2(const float* p, size_t stride, int
   return t;
 }
 
-template <int LW> struct WVec;
-template <> struct WVec<8> { typedef uint32_t type __attribute__((ext_vector_type(4))); };
-template <> struct WVec<4> { typedef uint32_t type __attribute__((ext_vector_type(2))); };
-template <> struct WVec<2> { typedef uint32_t type; };
-
-template <int LW>
-__device__ __forceinline__ void unpack_w(const typename WVec<LW>::type& v, float* wf) {
-  if constexpr (LW == 8) {
-    wf[0] = bflo(v.x); wf[1] = bfhi(v.x); wf[2] = bflo(v.y); wf[3] = bfhi(v.y);
-    wf[4] = bflo(v.z); wf[5] = bfhi(v.z); wf[6] = bflo(v.w); wf[7] = bfhi(v.w);
-  } else if constexpr (LW == 4) {
-    wf[0] = bflo(v.x); wf[1] = bfhi(v.x); wf[2] = bflo(v.y); wf[3] = bfhi(v.y);
-  } else {
-    wf[0] = bflo(v); wf[1] = bfhi(v);
-  }
-}
-
-// Index of activation element (row r, feature k) in the dot kernel's x layout: [row-block r/16][k/32][k%4][r%16][(k%32)/4].
-// A lane (s = row-in-block, q = k%4) of the MFMA A fragment then finds its 8 values of a 32-k quarter-group in 16 contiguous bytes.
-__host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
-  return (size_t)(r >> 4) * K * 16 + ((((size_t)(k >> 5) * 4 + (k & 3)) * 16 + (r & 15)) * 8 + ((k & 31) >> 2));
-}
-
 // =====================================================================================================
-// Canonical DOT (DenseGeneral, linears.py:188-232), two kernels over one x layout and one operation order:
-//   chain       16 consecutive k: a = 0; a = fma(x_k, w_kn, a)
-//   group       8 chains (128 k) added in order from 0
-//   super-group IXT_SG groups (512 k) added in order from 0        <- one f32 "slice" per super-group in split-K launches
-//   total       super-groups added in order from 0
-// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate) is bit-for-bit a k-ordered fmaf chain (CDNA4 guide, "FP32-input MFMA"),
-// so the matrix-core kernel and the vector-ALU kernel produce identical bits.
+// Canonical DOT (DenseGeneral, linears.py:188-232) on the bf16 matrix cores.
+//   One v_mfma_f32_16x16x32_bf16 accumulates, per output element, four steps of 8 consecutive k in ascending order; a step
+//   is an aligned, truncating integer add (measured on MI355X and restated bit for bit by the CPU checker used in tests,
+//   orc_mfma_step8).  The canonical order is therefore fixed by the instruction sequence:
+//     chain c : acc = 0; MFMAs over k in [512c, min(K, 512c+512)), ascending, all into the same accumulator
+//     total   : t = 0; t = t + chain(c), c ascending (plain f32 adds)   <- one f32 "slice" per chain in split-K launches
+//   Which wave runs which chain, how many rows share a weight fragment, split-K or not: free, the bits do not change.
+//
+// Fragment layouts (both operands are stored in HBM exactly as a lane reads them: 16 contiguous bytes per lane, 1 KiB per
+// wave-instruction, consecutive k-steps of one tile contiguous):
+//   activations x(r, k): [r/16][k/32][(k%32)/8][r%16][k%8]      (xidx; written by the producer kernels)
+//   weights     w(k, n): [n/16][k/32][(k%32)/8][n%16][k%8]      (widx; written once by ixt_load_weight)
+// MFMA roles: A = weights (A row i = column n of the layer), B = activations (B column j = activation row r), so a lane
+// ends up with 4 consecutive output columns of one row: one 16-byte store.
 // =====================================================================================================
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
 
-// =====================================================================================================
-// The same canonical DOT on the vector ALU (v_pk_fma_f32), for <= 8 activation rows per block (decode): at 8 rows the f32
-// matrix pipe gives no advantage (f32 MFMA rate = vector rate, and a 16-row instruction is half empty), while this
-// structure has every load of a block in flight at once and 8 waves per 128-k group.
-//   grid  = (ceil(N/(64 LW)), nsplit, ceil(R/RB));  block = 512 threads = 8 waves = the 8 chains of one group.
-//   wave w owns chain w: 16 k-rows x (64 LW) columns, one load per lane per k-row, LW columns x RB rows of f32 accumulators
-//   per lane; x comes in as SGPR operands (scalar loads).  The 8 chain results are added in chain order through LDS.
-//   SPLIT: every group sum goes to its own slice; !SPLIT: the block walks all groups and adds the group sums in order.
-// =====================================================================================================
-// LW = columns per lane (8: 16-B loads, tile 512 columns; 4: 8-B loads, tile 256; 2: 4-B loads, tile 128) -- a pure
-// parallelisation choice for matrices with few column tiles; the numerics do not depend on it.
-// EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded
-// to bf16, optionally stored as f32 logits, and each block emits its (max, first index) pair per row for k_argmax_final.
-template <int RB, int LW, bool SPLIT, int EPI, bool NT>
-__global__ __launch_bounds__(512, 4) void k_dot(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, int K, int N, int R,
-                                                float* __restrict__ out, int groups_per_block, float* __restrict__ amax_val,
-                                                int32_t* __restrict__ amax_idx) {
-  typedef typename WVec<LW>::type wvec_t;
-  constexpr int RH = (LW == 8 && RB > 4) ? 4 : RB;  // rows per accumulate/exchange pass (8 rows x 8 columns would not fit 128 VGPRs)
-  constexpr int TW = 64 * LW;          // tile width
-  constexpr int NP = 512 / TW;         // threads per column in the exchange
-  __shared__ __attribute__((aligned(16))) float red[8 * RH * TW];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int n0 = blockIdx.x * TW;
-  const int nl = n0 + lane * LW;
-  const bool col_ok = nl < N;
-  const int r0 = blockIdx.z * RB;
-  const int G = K / IXT_GL;
-  int g_begin = 0, g_end = G;
-  if (SPLIT) {   // one super-group per block
-    g_begin = blockIdx.y * IXT_SG;
-    g_end = min(G, g_begin + IXT_SG);
-  }
-  const int ocol = tid % TW, opart = tid / TW;
-  float tot[RB], sgs[RB];   // total over super-groups, running super-group sum
-#pragma unroll
-  for (int r = 0; r < RB; ++r) { tot[r] = 0.0f; sgs[r] = 0.0f; }
+__host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
+  return (size_t)(r >> 4) * K * 16 + (((size_t)(k >> 5) * 4 + ((k & 31) >> 3)) * 16 + (r & 15)) * 8 + (k & 7);
+}
+__host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xidx(n, k, K); }
 
-  for (int g = g_begin; g < g_end; ++g) {
-    const int kbase = g * IXT_GL + wave * IXT_CL;
-    wvec_t wv[IXT_CL];
-    if (col_ok) {
-      const bf16_t* wp = w + (size_t)kbase * N + nl;
-      // NT: weights of a decode step are read exactly once per step -> non-temporal, so they do not evict the partial
-      // slices and activations the next kernels re-read from L2 / Infinity Cache
+// EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded to
+// bf16, optionally stored as f32 logits, and each wave emits its (max, first index) pair per row for k_argmax_final.
+//   grid = (ceil(waves/WPB), SPLIT ? chains : 1, ceil(rowblocks/NRB)), block = WPB waves (blockDim.x / 64), LDS = NRB x 16 KiB.
+//   A block = WPB adjacent 16-column tiles x one chain at a time x NRB 16-row blocks.  Per chain: every wave first issues the
+//   loads of its 16 weight fragments (16 x 1 KiB, all in flight together, HBM), then the block copies the chain's activation
+//   slab (NRB x 16 fragments, L2) into LDS once for all its waves, and each wave runs 16 x NRB MFMAs reading the activation
+//   fragments from LDS.  Without the LDS copy every wave pulls the whole slab through L2 itself: 4x the weight bytes at 64 rows.
+//   TS (EPI only): a wave walks TS consecutive tiles keeping a running (max, first index).
+template <int NRB, bool SPLIT, int EPI, bool NT>
+__global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+                                                 float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
+                                                 int nwaves, int TS) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
+  const int tid = threadIdx.x, nthr = blockDim.x, wpb = nthr >> 6;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wid = blockIdx.x * wpb + wave;
+  const int nsteps = K >> 5, ntile = N >> 4;
+  const int nchains = (nsteps + 15) >> 4;
+  const int nrbk = (R + 15) >> 4;
+  const int rb0 = blockIdx.z * NRB;
+  const int c_begin = SPLIT ? (int)blockIdx.y : 0, c_end = SPLIT ? (int)blockIdx.y + 1 : nchains;
+  const int r_in = lane & 15, cq = lane >> 4;
+  float best[NRB];
+  int bidx[NRB];
 #pragma unroll
-      for (int kk = 0; kk < IXT_CL; ++kk) {
-        const wvec_t* pw = reinterpret_cast<const wvec_t*>(wp + (size_t)kk * N);
-        if constexpr (NT) wv[kk] = __builtin_nontemporal_load(pw);
-        else wv[kk] = *pw;
+  for (int b = 0; b < NRB; ++b) { best[b] = -INFINITY; bidx[b] = 0x7fffffff; }
+  // activation slab of chain c -> LDS (row block b at xs[b*1024 ...]: cs*64 consecutive 16-byte elements).  The slab loads
+  // are issued BEFORE the weight loads of the same chain: loads return in order, so the (L2-resident) slab lands and is
+  // written to LDS while the weight fragments are still on their way from HBM.
+#define IXT_XSTAGE(C_)                                                                                             \
+  do {                                                                                                             \
+    const int s0_ = (C_) * 16, cs_ = min(16, nsteps - s0_);                                                        \
+    for (int e = tid; e < NRB * cs_ * 64; e += nthr) {                                                             \
+      const int b = e / (cs_ * 64), rem = e - b * (cs_ * 64);                                                      \
+      xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0_) * 64 + rem] : u32x4(0);       \
+    }                                                                                                              \
+  } while (0)
+  for (int ti = 0; ti < TS; ++ti) {
+    const int tile = wid * TS + ti;
+    const bool tile_ok = wid < nwaves && tile < ntile;
+    const u32x4* wbase = wt + (size_t)(tile_ok ? tile : 0) * nsteps * 64 + lane;
+    f32x4 tot[NRB];
+#pragma unroll
+    for (int b = 0; b < NRB; ++b) tot[b] = f32x4(0.0f);
+    u32x4 wv[16];
+#define IXT_WLOAD(S_, STEP_)                                                                     \
+  do {                                                                                           \
+    if (tile_ok && (STEP_) < nsteps) {                                                           \
+      if constexpr (NT) wv[S_] = __builtin_nontemporal_load(wbase + (size_t)(STEP_) * 64);       \
+      else wv[S_] = wbase[(size_t)(STEP_) * 64];                                                 \
+    }                                                                                            \
+  } while (0)
+    if (ti > 0) __syncthreads();                        // every wave is done reading the previous slab
+    u32x4 xq[SPLIT ? NRB * 4 : 1];                      // split-K: one chain per block, slab fetched straight into registers first
+    if constexpr (SPLIT) {
+      const int cs_ = min(16, nsteps - c_begin * 16);
+#pragma unroll
+      for (int j = 0; j < NRB * 4; ++j) {
+        const int e = tid + j * nthr, b = e / (cs_ * 64), rem = e - b * (cs_ * 64);
+        xq[j] = (e < NRB * cs_ * 64 && rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + c_begin * 16) * 64 + rem] : u32x4(0);
       }
-    } else {
-#pragma unroll
-      for (int kk = 0; kk < IXT_CL; ++kk) wv[kk] = wvec_t(0);
     }
 #pragma unroll
-    for (int hh = 0; hh < RB / RH; ++hh) {
-      // ---- x for this pass: per row 4 scalar 8-byte loads from the dot x layout (xidx): for q = k%4 the wave's chain holds
-      //      k = kbase+q, +4, +8, +12 as 4 consecutive bf16 (rows past R re-read row R-1; never stored)
-      uint32_t xw[RH][4][2];
+    for (int s = 0; s < 16; ++s) IXT_WLOAD(s, c_begin * 16 + s);
+    for (int c = c_begin; c < c_end; ++c) {
+      const int s0 = c * 16;
+      const int cs = min(16, nsteps - s0);              // steps of this chain
+      if constexpr (SPLIT) {   // (split-K launches use 256-thread blocks: NRB * 4 slab elements per thread)
 #pragma unroll
-      for (int r = 0; r < RH; ++r) {
-        const int row = min(r0 + hh * RH + r, R - 1);
-        const bf16_t* xr = x + (size_t)(row >> 4) * K * 16 + ((size_t)(kbase >> 5) * 64 + (row & 15)) * 8 + ((kbase >> 4) & 1) * 4;
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const uint32_t* p2 = reinterpret_cast<const uint32_t*>(xr + (size_t)qq * 128);
-          xw[r][qq][0] = p2[0];
-          xw[r][qq][1] = p2[1];
+        for (int j = 0; j < NRB * 4; ++j) {
+          const int e = tid + j * nthr, b = e / (cs * 64), rem = e - b * (cs * 64);
+          if (e < NRB * cs * 64) xs[b * 1024 + rem] = xq[j];
         }
-      }
-      float acc[RH][LW];
-#pragma unroll
-      for (int r = 0; r < RH; ++r)
-#pragma unroll
-        for (int j = 0; j < LW; ++j) acc[r][j] = 0.0f;
-#pragma unroll
-      for (int kk = 0; kk < IXT_CL; ++kk) {
-        float wf[LW];
-        unpack_w<LW>(wv[kk], wf);
-#pragma unroll
-        for (int r = 0; r < RH; ++r) {
-          const uint32_t xd = xw[r][kk & 3][kk >> 3];
-          const float xv = ((kk >> 2) & 1) ? bfhi(xd) : bflo(xd);
-#pragma unroll
-          for (int j = 0; j < LW; ++j) acc[r][j] = __builtin_fmaf(xv, wf[j], acc[r][j]);
-        }
-      }
-      if (hh + 1 < RB / RH) {
-        // make the weight registers opaque so the next pass re-unpacks them instead of keeping 128 unpacked floats live
-#pragma unroll
-        for (int kk = 0; kk < IXT_CL; ++kk) asm volatile("" : "+v"(wv[kk]));
-      }
-      // ---- add the 8 chains of the group in chain order
-      if (hh > 0 || g > g_begin) __syncthreads();
-#pragma unroll
-      for (int r = 0; r < RH; ++r) {
-        float* dst = red + ((wave * RH + r) * TW) + lane * LW;
-#pragma unroll
-        for (int j = 0; j < LW; ++j) dst[j] = acc[r][j];
+      } else {
+        if (c > c_begin) __syncthreads();
+        IXT_XSTAGE(c);
       }
       __syncthreads();
+      f32x4 acc[NRB];
 #pragma unroll
-      for (int r = 0; r < RH; ++r) {
-        if (RH >= NP ? (r % NP == opart) : (opart == r)) {
-          float s = 0.0f;
+      for (int b = 0; b < NRB; ++b) acc[b] = f32x4(0.0f);
 #pragma unroll
-          for (int c = 0; c < IXT_NC; ++c) s = s + red[(c * RH + r) * TW + ocol];
-          const int row = r0 + hh * RH + r;
-          sgs[hh * RH + r] = sgs[hh * RH + r] + s;
-          if (((g + 1) % IXT_SG) == 0 || g + 1 == g_end) {   // super-group complete
-            if (SPLIT) {
-              if (row < R && n0 + ocol < N) out[((size_t)blockIdx.y * R + row) * N + n0 + ocol] = sgs[hh * RH + r];
-            } else {
-              tot[hh * RH + r] = tot[hh * RH + r] + sgs[hh * RH + r];
-            }
-            sgs[hh * RH + r] = 0.0f;
-          }
+      for (int s = 0; s < 16; ++s) {
+        if (s < cs) {
+          const bf16x8 wf = __builtin_bit_cast(bf16x8, wv[s]);
+#pragma unroll
+          for (int b = 0; b < NRB; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xs[b * 1024 + s * 64 + lane]), acc[b], 0, 0, 0);
+          if (!SPLIT && c + 1 < c_end) IXT_WLOAD(s, s0 + 16 + s);
+        }
+      }
+      if (SPLIT) {
+#pragma unroll
+        for (int b = 0; b < NRB; ++b) {
+          const int row = (rb0 + b) * 16 + r_in;
+          if (tile_ok && row < R)
+            *reinterpret_cast<float4*>(out + ((size_t)c * R + row) * N + tile * 16 + cq * 4) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < NRB; ++b) tot[b] = tot[b] + acc[b];
+      }
+    }
+#undef IXT_WLOAD
+#undef IXT_XSTAGE
+    if (!SPLIT && tile_ok) {
+#pragma unroll
+      for (int b = 0; b < NRB; ++b) {
+        const int row = (rb0 + b) * 16 + r_in;
+        if (EPI == 0) {
+          if (row < R)
+            *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[b][0], tot[b][1], tot[b][2], tot[b][3]);
+        } else {
+          // running (max, first index) over this wave's tiles (ascending columns: a later equal value never replaces)
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = rbf(tot[b][j]);
+          if (out != nullptr && row < R) *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (v[j] > best[b]) { best[b] = v[j]; bidx[b] = tile * 16 + cq * 4 + j; }
         }
       }
     }
   }
-  if (!SPLIT && EPI == 0) {
+  if (EPI == 1 && wid < nwaves) {
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const bool mine = (RH >= NP) ? ((r % RH) % NP == opart) : (opart == (r % RH));
-      if (mine && r0 + r < R && n0 + ocol < N) out[(size_t)(r0 + r) * N + n0 + ocol] = tot[r];
-    }
-  }
-  if (!SPLIT && EPI == 1) {
-    // tile of rounded logits in LDS: red[r][TW] (RB*TW <= 8*RH*TW floats)
-    __syncthreads();
+    for (int b = 0; b < NRB; ++b) {
+      float bv = best[b];
+      int bi = bidx[b];
 #pragma unroll
-    for (int r = 0; r < RB; ++r) {
-      const bool mine = (RH >= NP) ? ((r % RH) % NP == opart) : (opart == (r % RH));
-      if (mine) red[r * TW + ocol] = (n0 + ocol < N) ? rbf(tot[r]) : -INFINITY;
-    }
-    __syncthreads();
-    if (out != nullptr) {
-      for (int i = tid; i < RB * TW; i += 512) {
-        const int r = i / TW, c = i % TW;
-        if (r0 + r < R && n0 + c < N) out[(size_t)(r0 + r) * N + n0 + c] = red[i];
+      for (int off = 16; off < 64; off <<= 1) {   // the 4 lanes of a row are lanes r, r+16, r+32, r+48
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
-    }
-    if (wave < RB && r0 + wave < R) {
-      float best = -INFINITY;
-      int bidx = 0x7fffffff;
-#pragma unroll
-      for (int c = lane; c < TW; c += 64) {
-        const float v = red[wave * TW + c];
-        if (v > best) { best = v; bidx = n0 + c; }   // ascending c: first index wins ties
-      }
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-      }
-      if (lane == 0) {
-        amax_val[(size_t)(r0 + wave) * gridDim.x + blockIdx.x] = best;
-        amax_idx[(size_t)(r0 + wave) * gridDim.x + blockIdx.x] = bidx;
+      const int row = (rb0 + b) * 16 + r_in;
+      if (cq == 0 && row < R) {
+        amax_val[(size_t)row * nwaves + wid] = bv;
+        amax_idx[(size_t)row * nwaves + wid] = bi;
       }
     }
   }
 }
 
-// =====================================================================================================
-// Matrix-core DOT, one memory round trip per group: block = 4 waves = one 128-k group x 128 columns; wave v owns chains
-// 2v, 2v+1 (32 k): its 8 weight loads + 1 x load are all issued before the first MFMA; the 8 chain results of the group are
-// exchanged through LDS and added in chain order (thread t owns row t/16, columns 8(t%16)..+7).
-// grid = (ceil(N/128), nsplit, ceil(R/16)), block 256, LDS 64 KiB.
-// =====================================================================================================
-// NRB = 16-row blocks handled by one thread block with the SAME loaded weights (1: <= 16 rows, 2: <= 32, 4: <= 64 per
-// blockIdx.z): the weights of a group are loaded once and reused from registers for every row block.
-template <bool SPLIT, int EPI, bool NT, int NRB>
-__global__ __launch_bounds__(256, 2) void k_dotg(const bf16_t* __restrict__ xT, const bf16_t* __restrict__ w, int K, int N, int R,
-                                                 float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
-                                                 int ntiles) {
-  // (an exchange of 8 rows at a time in 32 KiB -- four blocks per CU -- measured slower: the extra barriers cost more than the occupancy buys)
-  __shared__ __attribute__((aligned(16))) float red[8 * 16 * 128];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int s = lane & 15, q = lane >> 4;
-  const int tile = blockIdx.x;
-  const int n0 = tile * 128, nl = n0 + s * 8;
-  const bool col_ok = nl < N;
-  const int rz0 = blockIdx.z * NRB;                       // first 16-row block of this thread block
-  const int G = K / IXT_GL;
-  int g_begin = 0, g_end = G;
-  if (SPLIT) { g_begin = blockIdx.y * IXT_SG; g_end = min(G, g_begin + IXT_SG); }   // one super-group per block
-  // reducer role
-  const int orow = tid >> 4, ocol = (tid & 15) * 8;
-  float tot[NRB][8], sgs[NRB][8];   // total over super-groups, running super-group sum
-#pragma unroll
-  for (int b = 0; b < NRB; ++b)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { tot[b][j] = 0.0f; sgs[b][j] = 0.0f; }
-
-  u32x4 wq[8];
-  u32x4 xq[NRB];
-#define IXT_LOAD_G(G_)                                                                                    \
-  do {                                                                                                    \
-    const int qg_ = (G_) * 4 + wave;   /* quarter-group = this wave's 2 chains */                         \
-    _Pragma("unroll") for (int b_ = 0; b_ < NRB; ++b_)                                                    \
-      xq[b_] = ((rz0 + b_) * 16 < R) ? *reinterpret_cast<const u32x4*>(xT + (size_t)(rz0 + b_) * K * 16 + (((size_t)qg_ * 4 + q) * 16 + s) * 8) : u32x4(0); \
-    const bf16_t* wrow_ = w + (size_t)(qg_ * 32 + q) * N + nl;                                            \
-    _Pragma("unroll") for (int t_ = 0; t_ < 8; ++t_) {                                                    \
-      const u32x4* pw_ = reinterpret_cast<const u32x4*>(wrow_ + (size_t)(4 * t_) * N);                    \
-      if (!col_ok) wq[t_] = u32x4(0);                                                                     \
-      else if constexpr (NT) wq[t_] = __builtin_nontemporal_load(pw_);                                    \
-      else wq[t_] = *pw_;                                                                                 \
-    }                                                                                                     \
-  } while (0)
-  IXT_LOAD_G(g_begin);
-  for (int g = g_begin; g < g_end; ++g) {
-    u32x4 wc[8];
-    u32x4 xc[NRB];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) wc[t] = wq[t];
-#pragma unroll
-    for (int b = 0; b < NRB; ++b) xc[b] = xq[b];
-    if (g + 1 < g_end) IXT_LOAD_G(g + 1);   // next group's loads fly during this group's MFMAs and exchanges
-#pragma unroll
-    for (int b = 0; b < NRB; ++b) {
-      if ((rz0 + b) * 16 < R) {
-        if (b > 0 || g > g_begin) __syncthreads();   // previous readers of red are done
-#pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          f32x4 acc[8];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) acc[j] = f32x4(0.0f);
-#pragma unroll
-          for (int t = 0; t < 4; ++t) {
-            const int i = c * 4 + t;
-            const uint32_t xd = xc[b][i >> 1];
-            const float a = (i & 1) ? bfhi(xd) : bflo(xd);
-            const u32x4 wv = wc[i];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.x), acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.x), acc[1], 0, 0, 0);
-            acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.y), acc[2], 0, 0, 0);
-            acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.y), acc[3], 0, 0, 0);
-            acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.z), acc[4], 0, 0, 0);
-            acc[5] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.z), acc[5], 0, 0, 0);
-            acc[6] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bflo(wv.w), acc[6], 0, 0, 0);
-            acc[7] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfhi(wv.w), acc[7], 0, 0, 0);
-          }
-          // chain (2*wave + c) -> red[chain][row][col]
-          float* dst = red + ((size_t)(wave * 2 + c) * 16) * 128 + s * 8;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float* d2 = dst + (q * 4 + r) * 128;
-            *reinterpret_cast<float4*>(d2) = make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]);
-            *reinterpret_cast<float4*>(d2 + 4) = make_float4(acc[4][r], acc[5][r], acc[6][r], acc[7][r]);
-          }
-        }
-        __syncthreads();
-        float sum[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum[j] = 0.0f;
-#pragma unroll
-        for (int c = 0; c < IXT_NC; ++c) {
-          const float* src = red + ((size_t)c * 16 + orow) * 128 + ocol;
-          const float4 a0 = *reinterpret_cast<const float4*>(src);
-          const float4 a1 = *reinterpret_cast<const float4*>(src + 4);
-          sum[0] = sum[0] + a0.x; sum[1] = sum[1] + a0.y; sum[2] = sum[2] + a0.z; sum[3] = sum[3] + a0.w;
-          sum[4] = sum[4] + a1.x; sum[5] = sum[5] + a1.y; sum[6] = sum[6] + a1.z; sum[7] = sum[7] + a1.w;
-        }
-        const int row = (rz0 + b) * 16 + orow;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sgs[b][j] = sgs[b][j] + sum[j];
-        if (((g + 1) % IXT_SG) == 0 || g + 1 == g_end) {   // super-group complete
-          if (SPLIT) {
-            if (row < R && n0 + ocol < N) {
-              float* dst = out + ((size_t)blockIdx.y * R + row) * N + n0 + ocol;
-              *reinterpret_cast<float4*>(dst) = make_float4(sgs[b][0], sgs[b][1], sgs[b][2], sgs[b][3]);
-              *reinterpret_cast<float4*>(dst + 4) = make_float4(sgs[b][4], sgs[b][5], sgs[b][6], sgs[b][7]);
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) tot[b][j] = tot[b][j] + sgs[b][j];
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) sgs[b][j] = 0.0f;
-        }
-      }
-    }
-  }
-#undef IXT_LOAD_G
-  if (!SPLIT) {
-#pragma unroll
-    for (int b = 0; b < NRB; ++b) {
-      const int row = (rz0 + b) * 16 + orow;
-      const bool ok = row < R && n0 + ocol < N;
-      if (EPI == 0) {
-        if (ok) {
-          float* dst = out + (size_t)row * N + n0 + ocol;
-          *reinterpret_cast<float4*>(dst) = make_float4(tot[b][0], tot[b][1], tot[b][2], tot[b][3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(tot[b][4], tot[b][5], tot[b][6], tot[b][7]);
-        }
-      } else {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = rbf(tot[b][j]);
-        if (ok && out != nullptr) {
-          float* dst = out + (size_t)row * N + n0 + ocol;
-          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-        float best = -INFINITY;
-        int bidx = 0x7fffffff;
-        if (n0 + ocol < N) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (v[j] > best) { best = v[j]; bidx = n0 + ocol + j; }
-        }
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {   // the 16 threads of a row are 16 consecutive lanes
-          const float ov = __shfl_xor(best, off, 64);
-          const int oi = __shfl_xor(bidx, off, 64);
-          if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-        }
-        if ((tid & 15) == 0 && row < R) {
-          amax_val[(size_t)row * ntiles + tile] = best;
-          amax_idx[(size_t)row * ntiles + tile] = bidx;
-        }
-      }
-    }
-  }
+// weights: row-major [K][ncols] (bf16 or f32) -> the tiled fragment layout of a [K][*] matrix, columns n_off..n_off+ncols
+template <typename T>
+__global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)K * ncols) return;
+  const int k = (int)(i / ncols), n = (int)(i % ncols);
+  bf16_t v;
+  if constexpr (sizeof(T) == 2) v = src[i]; else v = f2bf(src[i]);
+  dst[widx(k, n_off + n, K)] = v;
 }
 
 // x [R][K] row-major bf16 -> the dot kernel's x layout (op-level entry point only; the model's producers write it directly)
@@ -580,14 +375,10 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
     bf16_t o[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) o[j] = f2bf(rbf(hrow[ch * 8 + j] * rs) * sc[j]);
-    if (a.xn_kmajor) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) a.xn_out[xidx(r, ch * 8 + j, E)] = o[j];
-    } else {
-      u32x4 ov;
-      ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
-      *reinterpret_cast<u32x4*>(a.xn_out + (size_t)r * E + ch * 8) = ov;
-    }
+    u32x4 ov;
+    ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+    // in the dot kernel's x layout 8 consecutive features of a row are one lane's 16 bytes
+    *reinterpret_cast<u32x4*>(a.xn_out + (a.xn_kmajor ? xidx(r, ch * 8, E) : (size_t)r * E + ch * 8)) = ov;
   }
 }
 

@@ -67,6 +67,8 @@ def lib():
     _lib.orc_rmsnorm.argtypes = [_u16p, _u16p, _u16p, ctypes.c_int, ctypes.c_float]
     _lib.orc_rope.argtypes = [_u16p, ctypes.c_int, ctypes.c_int, _u16p, _u16p]
     _lib.orc_dot_rows.argtypes = [_u16p, ctypes.c_int, ctypes.c_int, _u16p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int]
+    _lib.orc_dot_rows_scalar.argtypes = _lib.orc_dot_rows.argtypes
+    _lib.orc_mfma_cases.argtypes = [_u16p, _u16p, _f32p, _f32p, ctypes.c_int64]
     _lib.orc_attend_row.argtypes = [ctypes.POINTER(_CModel), ctypes.c_int, _u16p, _i32p, ctypes.c_int, _u16p, _f32p]
     _lib.orc_f32_to_bf16.argtypes = [_f32p, _u16p, ctypes.c_int64]
     _lib.orc_exp_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]

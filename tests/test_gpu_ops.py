@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
   import torch
-  cfg = H.make_config(per_device_batch_size=4.0)
+  cfg = H.make_config(per_device_batch_size=64.0, pagedattn_num_pages=256)   # 64 rows: every row-block variant of the dot fits the scratch
   weights = H.synth.synth_weights(cfg, 0)
   eng, _ = H.make_engine(cfg, weights)
   from oracle import oracle as O
@@ -29,19 +29,47 @@ def _vp(t):
   return ctypes.c_void_p(t.data_ptr())
 
 
-@pytest.mark.parametrize("R,K,N", [(1, 256, 512), (3, 128, 8), (8, 384, 520), (5, 1024, 1536), (17, 256, 1000), (2, 2048, 264)])
-def test_dot(ctx, R, K, N):
+def _dot_case(ctx, x, w):
   torch, eng, O = ctx["torch"], ctx["eng"], ctx["O"]
-  rng = np.random.default_rng(R * 1000 + K + N)
-  x = H.rand_bf16(rng, (R, K))
-  w = H.rand_bf16(rng, (K, N), 0.05)
+  R, K = x.shape
+  N = w.shape[1]
   ref = np.zeros((R, N), np.float32)
   O.lib().orc_dot_rows(O._p(x, O._u16p), K, R, O._p(w, O._u16p), K, N, O._p(ref, O._f32p), N)
   xd, wd = H.dev_bf16(x), H.dev_bf16(w)
   out = torch.empty((R, N), dtype=torch.float32, device="cuda")
   H.lib.check(eng.lib.ixt_op_dot(eng._ctx, _vp(xd), _vp(wd), _vp(out), R, K, N, _st(torch)))
   got = out.cpu().numpy()
-  assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+  bad = np.flatnonzero(got.view(np.uint32).ravel() != ref.view(np.uint32).ravel())
+  assert bad.size == 0, f"{bad.size} of {R * N} outputs differ, first at {bad[:4]}: {got.ravel()[bad[:4]]} vs {ref.ravel()[bad[:4]]}"
+
+
+# rows: 1..8 (one partly filled row block), 17/40/64 (2, 3->4, 4 row blocks sharing weights), 100 (two launches of row blocks);
+# K: single chain (<= 512), several chains, a short last chain (640, 1152)
+@pytest.mark.parametrize("R,K,N", [(1, 256, 512), (3, 128, 16), (8, 384, 528), (5, 1024, 1536), (17, 256, 1008), (2, 2048, 272),
+                                   (40, 640, 512), (64, 1152, 256), (100, 2048, 128), (16, 512, 64)])
+def test_dot(ctx, R, K, N):
+  rng = np.random.default_rng(R * 1000 + K + N)
+  _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+
+
+@pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
+def test_dot_wide_exponents_and_zeros(ctx, spread, zero_frac):
+  """The matrix-core arithmetic truncates small products against the largest one of each 8-k step: exercise wide exponent
+  ranges, exact zeros and cancellation, where an fma-chain model and the hardware differ most."""
+  rng = np.random.default_rng(spread)
+  R, K, N = 24, 1024, 256
+  x = rng.standard_normal((R, K)) * np.exp2(rng.integers(-spread, spread + 1, (R, K)))
+  w = rng.standard_normal((K, N)) * np.exp2(rng.integers(-spread, spread + 1, (K, N)))
+  x[rng.random((R, K)) < zero_frac] = 0
+  w[rng.random((K, N)) < zero_frac] = 0
+  w[:, 7] = -w[:, 6]                       # exact cancellation between neighbouring columns' products
+  x[3, :] = 0                              # an all-zero activation row
+  _dot_case(ctx, O_bf16(x), O_bf16(w))
+
+
+def O_bf16(a):
+  from oracle import oracle as O
+  return O.f32_to_bf16(np.ascontiguousarray(a, np.float32))
 
 
 @pytest.mark.parametrize("E", [256, 768, 2048, 2304])
