@@ -148,6 +148,12 @@ int ixt_timing_enable(ixt_ctx* ctx, int enable);
 int ixt_timing_reset(ixt_ctx* ctx);
 int ixt_timing_get(ixt_ctx* ctx, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch);
 
+
+/* Launch-shape knobs of this build (no counterpart in the reference; results never depend on them, tests use them to drive
+ * every kernel variant on small configurations):
+ *   "attn_fused_min_blocks"  decode attention runs as one launch per layer once rows x kv_heads reaches this (default 128) */
+int ixt_set_option(ixt_ctx* ctx, const char* name, int value);
+
 #ifdef __cplusplus
 }
 #endif

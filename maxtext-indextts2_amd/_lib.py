@@ -62,6 +62,7 @@ SIGNATURES = {
     "ixt_timing_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "ixt_timing_reset": (ctypes.c_int, [vp]),
     "ixt_timing_get": (ctypes.c_int, [vp, ctypes.c_char_p, c_f64p, c_i64p, c_f64p]),
+    "ixt_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int]),
 }
 
 _lib = None

@@ -72,6 +72,7 @@ struct ixt_ctx {
   AttnGeom geom{};
   // timing
   bool timing = false;
+  int attn_fused_min_blocks = 128;
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
   // graphs keyed by the pointer tuple of ixt_generate
@@ -578,6 +579,32 @@ static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStre
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
 }
 
+template <int HD, int GQ>
+static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr, hipStream_t st) {
+  const AttnGeom& g = c->geom;
+  DecAttnArgs da;
+  da.part = c->part; da.slices = dr.slices; da.slice_stride = dr.slice_stride; da.ncols = c->NQKV;
+  da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
+  da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
+  da.kpages = c->kpages + (size_t)layer * c->layer_page_elems; da.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  da.out = c->ao; da.g = g;
+  const size_t lds = sizeof(float) * ((size_t)GQ * HD + 2 * HD + (size_t)GQ * g.Tmax + g.mpg + 8 + (size_t)g.nsb_max * HD);
+  hipLaunchKernelGGL((k_attn_decode<HD, GQ>), dim3(R, g.nkv), dim3(256), lds, st, da);
+}
+
+// decode rows, enough (row, kv head) pairs to fill the chip: the whole attention in one launch (writes c->ao)
+static int launch_attention_fused(ixt_ctx* c, int layer, int R, const DotResult& qkv, hipStream_t st) {
+#define ATT(HD_, GQ_)                                                                             \
+  if (c->D == HD_ && c->GQ == GQ_) {                                                              \
+    launch_decode_attn<HD_, GQ_>(c, layer, R, qkv, st);                                           \
+    LAUNCHCHK();                                                                                  \
+    return IXT_OK;                                                                                \
+  }
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
+}
+
 // attention up to the per-super-block partials (c->pvpart); decode rows use the fused front kernel
 static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint, const DotResult& qkv, bool decode, hipStream_t st) {
 #define ATT(HD_, GQ_)                                                                             \
@@ -617,9 +644,16 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
       LAUNCHCHK();
     }
-    TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));
-    hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
-    LAUNCHCHK();
+    // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
+    const int fused_min = c->attn_fused_min_blocks;
+    const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * c->geom.Tmax + c->geom.mpg + 8 + (size_t)c->geom.nsb_max * c->D);
+    if (decode && R * c->KV >= fused_min && fused_lds <= 64 * 1024) {
+      TRY(launch_attention_fused(c, l, R, dr, st));
+    } else {
+      TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));
+      hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
+      LAUNCHCHK();
+    }
     TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
     TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
     TRY(launch_dot(c, c->xn, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
@@ -816,7 +850,20 @@ extern "C" int ixt_rope_tables(ixt_ctx* c, uint16_t* sin_out, uint16_t* cos_out)
   return IXT_OK;
 }
 
-// --------------------------------------------------------------------------------------- timing
+// --------------------------------------------------------------------------------------- options, timing
+extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
+  if (!c || !name) return set_err(IXT_ERR_INVALID, "null argument");
+  if (strcmp(name, "attn_fused_min_blocks") == 0) {
+    if (value < 1) return set_err(IXT_ERR_RANGE, "attn_fused_min_blocks must be positive");
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launch sequences embed the old choice
+    c->graphs.clear();
+    c->attn_fused_min_blocks = value;
+    return IXT_OK;
+  }
+  return set_err(IXT_ERR_INVALID, "unknown option %s", name);
+}
+
 extern "C" int ixt_timing_enable(ixt_ctx* c, int enable) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
   c->timing = enable != 0;

@@ -768,6 +768,218 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
   }
 }
 
+// ---- steps 1-4 in ONE launch for decode rows: block = (row, kv head) owns the whole key range of its row.
+//      QKV slice sums + RoPE + K/V page write (as k_attn_front_decode), scores into LDS, softmax statistics once, PV per
+//      super-block, the in-order sum over super-blocks through LDS, bf16 output in the dot kernel's x layout.  No score /
+//      partial round trip through HBM, no per-split recomputation of the softmax, and the first key tile is already in
+//      flight while the prologue runs.  The new token's K and V are taken from LDS, never from the page being written.
+//      Same operation order as the split kernels (scores: one fma chain over d; l: page sums in key order, pages in order;
+//      PV: page chains, 4 pages per super-block in order, super-blocks in order).  grid = (R, nkv), block 256.
+struct DecAttnArgs {
+  const float* part; int slices; size_t slice_stride; int ncols;
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
+  const bf16_t* rope_sin; const bf16_t* rope_cos;
+  bf16_t* kpages; bf16_t* vpages;
+  bf16_t* out;        // [R][nq*hd] in xidx layout
+  AttnGeom g;
+};
+
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const AttnGeom& g = a.g;
+  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n_out = g.nq * HD;
+  if (!a.row_active[r]) {
+    for (int i = tid; i < GQ * HD; i += 256) a.out[xidx(r, kvh * GQ * HD + i, n_out)] = 0;
+    return;
+  }
+  float* qs = sm;                               // [GQ][HD]
+  float* kn = qs + GQ * HD;                     // [HD] new key (bf16-rounded, as f32)
+  float* vn = kn + HD;                          // [HD] new value
+  float* ebuf = vn + HD;                        // [GQ][Tmax] scores -> exps -> P
+  float* psum = ebuf + (size_t)GQ * g.Tmax;     // [mpg]
+  float* wred = psum + g.mpg;                   // [8]
+  float* sbs = wred + 8;                        // [nsb_max][HD] super-block sums of the head being finished
+  const int pos = a.row_pos[r];
+  const int kv_len = pos + 1;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  const int ppw = 64 / g.P;
+  constexpr int half = HD / 2;
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+  const int QN = g.nq * HD, KN = g.nkv * HD;
+
+  // first key tile of this wave: loads issued before the prologue
+  u32x4 kv[HD / 8];
+#define IXT_KLOAD(DST_, PS_)                                                                                      \
+  do {                                                                                                            \
+    const int pidx_ = (PS_) * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                    \
+    if ((PS_) * ppw < pages && j_ < kv_len && j_ != pos) {                                                        \
+      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, 0, lane % g.P);                               \
+      _Pragma("unroll") for (int dc = 0; dc < HD / 8; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
+    }                                                                                                             \
+  } while (0)
+  IXT_KLOAD(kv, wave);
+
+  // prologue: q heads, new k, new v of this kv head from the QKV slices (+ RoPE), K/V page write
+  for (int idx = tid; idx < (GQ + 2) * half; idx += 256) {
+    const int which = idx / half, i = idx % half;   // 0..GQ-1: q heads, GQ: k, GQ+1: v
+    int col0;
+    if (which < GQ) col0 = (kvh * GQ + which) * HD;
+    else if (which == GQ) col0 = QN + kvh * HD;
+    else col0 = QN + KN + kvh * HD;
+    const float* pq = a.part + (size_t)r * a.ncols + col0;
+    float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
+    float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+    if (which <= GQ) {
+      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
+      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
+      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
+      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      v1 = o1; v2 = o2;
+    }
+    const int page = prow[pos / g.P], tok = pos % g.P;
+    if (which < GQ) {
+      qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+    } else if (which == GQ) {
+      kn[i] = v1; kn[half + i] = v2;
+      a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
+      a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+    } else {
+      vn[i] = v1; vn[half + i] = v2;
+      bf16_t* vd = a.vpages + vpage_off(g, page, kvh, tok);
+      vd[i] = f2bf(v1); vd[half + i] = f2bf(v2);
+    }
+  }
+  __syncthreads();
+
+  // scores: lane = key; the next tile's loads are issued before the current tile's fma chains
+  for (int ps = wave; ps * ppw < pages; ps += 4) {
+    u32x4 kx[HD / 8];
+    IXT_KLOAD(kx, ps + 4);
+    const int pidx = ps * ppw + lane / g.P, j = pidx * g.P + lane % g.P;
+    if (j < kv_len) {
+      float acc[GQ];
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) acc[q] = 0.0f;
+      if (j == pos) {
+#pragma unroll 8
+        for (int d = 0; d < HD; ++d) {
+#pragma unroll
+          for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);
+        }
+      } else {
+#pragma unroll
+        for (int dc = 0; dc < HD / 8; ++dc) {
+          const float kf[8] = {bflo(kv[dc].x), bfhi(kv[dc].x), bflo(kv[dc].y), bfhi(kv[dc].y),
+                               bflo(kv[dc].z), bfhi(kv[dc].z), bflo(kv[dc].w), bfhi(kv[dc].w)};
+#pragma unroll
+          for (int q = 0; q < GQ; ++q) {
+            const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8);
+            const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8 + 4);
+            float sacc = acc[q];
+            sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);
+            sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);
+            sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);
+            sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);
+            acc[q] = sacc;
+          }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * g.Tmax + j] = acc[q];
+    }
+#pragma unroll
+    for (int dc = 0; dc < HD / 8; ++dc) kv[dc] = kx[dc];
+  }
+#undef IXT_KLOAD
+  __syncthreads();
+
+  constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
+  constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
+  const int tq = lane / LPP, dc = lane % LPP;
+  for (int q = 0; q < GQ; ++q) {
+    float* e = ebuf + (size_t)q * g.Tmax;
+    // max (order independent), exp, page sums in key order, l in page order, P
+    float m = -INFINITY;
+    for (int j = tid; j < kv_len; j += 256) m = fmaxf(m, e[j]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) wred[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+    for (int j = tid; j < kv_len; j += 256) e[j] = ixt_exp(e[j] - m);
+    __syncthreads();
+    for (int p = tid; p < pages; p += 256) {
+      float sacc = 0.0f;
+      const int e1 = min((p + 1) * g.P, kv_len);
+      for (int j = p * g.P; j < e1; ++j) sacc = sacc + e[j];
+      psum[p] = sacc;
+    }
+    __syncthreads();
+    float l = 0.0f;
+    for (int p = 0; p < pages; ++p) l = l + psum[p];
+    for (int j = tid; j < kv_len; j += 256) e[j] = rbf(e[j] / l);
+    __syncthreads();
+    // PV: one wave-iteration = PPW pages = PPW/4 super-blocks
+    for (int pg0 = wave * PPW; pg0 < pages; pg0 += 4 * PPW) {
+      const int p = pg0 + tq;
+      float acc[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+      if (p < pages) {
+        const bf16_t* vp = a.vpages + vpage_off(g, prow[p], kvh, 0) + dc * 8;
+        const int ntok = min(g.P, kv_len - p * g.P);
+        const float* pj = e + (size_t)p * g.P;
+        for (int t0 = 0; t0 < ntok; t0 += 8) {
+          u32x4 vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            vv[u] = (t0 + u < ntok) ? *reinterpret_cast<const u32x4*>(vp + (size_t)(t0 + u) * HD) : u32x4(0);
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            if (t0 + u < ntok) {
+              float vf[8] = {bflo(vv[u].x), bfhi(vv[u].x), bflo(vv[u].y), bfhi(vv[u].y), bflo(vv[u].z), bfhi(vv[u].z), bflo(vv[u].w), bfhi(vv[u].w)};
+              if (p * g.P + t0 + u == pos) {   // the token this block has just written: its value comes from LDS
+#pragma unroll
+                for (int j = 0; j < 8; ++j) vf[j] = vn[dc * 8 + j];
+              }
+              const float pv = pj[t0 + u];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);
+            }
+          }
+        }
+      }
+      const int sbl = tq / IXT_SB;            // super-block within the wave-iteration
+      const int base_lane = sbl * IXT_SB * LPP + dc;
+      float ss[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ss[j] = 0.0f;
+#pragma unroll
+      for (int i = 0; i < IXT_SB; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ss[j] = ss[j] + __shfl(acc[j], base_lane + i * LPP, 64);
+      }
+      const int sb = pg0 / IXT_SB + sbl;
+      if (tq % IXT_SB == 0 && sb < nsb) {
+        float* dst = sbs + (size_t)sb * HD + dc * 8;
+        *reinterpret_cast<float4*>(dst) = make_float4(ss[0], ss[1], ss[2], ss[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(ss[4], ss[5], ss[6], ss[7]);
+      }
+    }
+    __syncthreads();
+    if (tid < HD) {
+      float t = 0.0f;
+      for (int sb = 0; sb < nsb; ++sb) t = t + sbs[(size_t)sb * HD + tid];
+      a.out[xidx(r, (kvh * GQ + q) * HD + tid, n_out)] = f2bf(t);
+    }
+    __syncthreads();
+  }
+}
+
 // ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const int32_t* row_pos, const int32_t* row_active,
                                                       bf16_t* out, AttnGeom g, int kmajor) {

@@ -17,10 +17,12 @@ def assert_pages_equal(eng, orc):
     assert np.array_equal(st[f], getattr(orc.page_state, f)), f
 
 
-def run_pair(cfg, weights, prompts, steps, use_graph=True, check_logits=True, chunks=None):
+def run_pair(cfg, weights, prompts, steps, use_graph=True, check_logits=True, chunks=None, options=None):
   """prompts: list of (padded_tokens, true_length) one per slot (len <= batch).  Returns HIP token matrix."""
   import torch
   eng, params = H.make_engine(cfg, weights)
+  for name, value in (options or {}).items():
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, name.encode(), int(value)))
   orc = H.make_oracle(cfg, weights)
   B = int(cfg.per_device_batch_size)
   prefixes, oprefixes = [], []
@@ -101,6 +103,19 @@ def test_tiny_batched_ragged(B, nprompts):
   run_pair(cfg, w, prompts, steps=40 if B <= 8 else 12, check_logits=B <= 20)
 
 
+@pytest.mark.parametrize("B,nprompts", [(1, 1), (4, 3), (20, 13)])
+def test_tiny_one_launch_decode_attention(B, nprompts):
+  """The decode attention as ONE launch per layer (block = row x kv head; the default from rows x kv_heads >= 128) forced onto
+  small batches: ragged lengths, inactive slots, 2 query heads per kv head, page-boundary crossings during the 40 steps."""
+  cfg = H.make_config(per_device_batch_size=float(B), pagedattn_num_pages=max(160, B * 10 + 1))
+  w = H.synth.synth_weights(cfg, 5)
+  prompts = []
+  for s in range(nprompts):
+    toks, _ = H.synth.synth_prompt(cfg.vocab_size, cfg.max_prefill_predict_length, 300 + s)
+    prompts.append((toks, [32, 1, 9, 17, 8, 31, 16, 24][s % 8]))
+  run_pair(cfg, w, prompts, steps=40, options={"attn_fused_min_blocks": 1})
+
+
 def test_tiny_graph_equals_eager():
   cfg_g = H.make_config(per_device_batch_size=2.0, ixt_use_hip_graph=True)
   cfg_e = H.make_config(per_device_batch_size=2.0, ixt_use_hip_graph=False)
@@ -126,15 +141,17 @@ def test_tiny_chunked_prefill():
   del eng
 
 
-def test_head_dim_128_mha_page32():
-  """C2's attention geometry (head_dim 128, MHA, 32-token pages) on a small body."""
+@pytest.mark.parametrize("fused", [False, True])
+def test_head_dim_128_mha_page32(fused):
+  """C2's attention geometry (head_dim 128, MHA, 32-token pages) on a small body; key ranges of up to 9 pages = 3 super-blocks,
+  through the split kernels and through the one-launch decode attention."""
   cfg = H.make_config(base_emb_dim=256, base_num_query_heads=2, base_num_kv_heads=2, head_dim=128, base_mlp_dim=384,
                       base_num_decoder_layers=2, vocab_size=2048, model_name="default", per_device_batch_size=2.0,
                       max_prefill_predict_length=64, max_target_length=320, pagedattn_tokens_per_page=32, pagedattn_num_pages=24)
   w = H.synth.synth_weights(cfg, 4)
   p0 = H.synth.synth_prompt(cfg.vocab_size, 64, 1)
   p1 = H.synth.synth_prompt(cfg.vocab_size, 64, 2)
-  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False)
+  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"attn_fused_min_blocks": 1} if fused else None)
 
 
 def test_release_and_reuse_slot():
