@@ -425,7 +425,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   int nrb = rowblocks >= 3 ? 4 : rowblocks;
   if (nrb_env == 1 || nrb_env == 2 || nrb_env == 4) nrb = nrb_env;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
-  bool split = !force_full && !epi_argmax && chains > 1 && zblocks == 1;
+  bool split = !force_full && !epi_argmax && chains > 1;
   if (split && (size_t)chains * R * N > out_floats) split = false;
   if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
   const int TS = epi_argmax ? (ts_env > 0 ? ts_env : 1) : 1;
@@ -443,15 +443,15 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
   const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
   {
-    dim3 grid((nwaves + wpb - 1) / wpb, split ? chains : 1, zblocks);
+    dim3 grid(((nwaves + wpb - 1) / wpb) * zblocks, split ? chains : 1, 1);
     const dim3 block(64 * wpb);
     const size_t lds = (size_t)nrb * 16 * 1024;
     const u32x4* xp = reinterpret_cast<const u32x4*>(x);
     const u32x4* wp = reinterpret_cast<const u32x4*>(w);
 #define DOTB(B_, S_, E_)                                                                                                        \
   do {                                                                                                                          \
-    if (nt) hipLaunchKernelGGL((k_dotb<B_, S_, E_, true>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS);     \
-    else hipLaunchKernelGGL((k_dotb<B_, S_, E_, false>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS);       \
+    if (nt) hipLaunchKernelGGL((k_dotb<B_, S_, E_, true>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS, zblocks);     \
+    else hipLaunchKernelGGL((k_dotb<B_, S_, E_, false>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS, zblocks);       \
   } while (0)
 #define DOTB_B(S_, E_) do { if (nrb == 4) DOTB(4, S_, E_); else if (nrb == 2) DOTB(2, S_, E_); else DOTB(1, S_, E_); } while (0)
     if (epi_argmax) DOTB_B(false, 1);
@@ -470,9 +470,23 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
 
 // logits (optional store) + greedy argmax for R rows of normed hidden states
 static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
-  DotResult dr;
-  TRY(launch_dot(c, yT, c->logits_w, c->E, c->V, R, logits_out, (size_t)R * c->V, true, st, &dr, true));
-  hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, dr.ntiles, argmax_out);
+  const int K = c->E, N = c->V;
+  const int ntile = N / 16, nwaves = (ntile + 3) / 4;
+  const int rowblocks = (R + 15) / 16;
+  const int nrb = rowblocks >= 3 ? 4 : rowblocks;
+  const int zblocks = (rowblocks + nrb - 1) / nrb;
+  if (zblocks != 1) return set_err(IXT_ERR_UNSUPPORTED, "unembedding of more than 64 rows in one call");
+  if ((size_t)R * nwaves > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+  const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (logits_out ? (double)R * N * 4.0 : 0.0));
+  dim3 grid((nwaves + 3) / 4, 1, zblocks);
+  const size_t lds = (size_t)nrb * 16 * 1024;
+  const u32x4* xp = reinterpret_cast<const u32x4*>(yT);
+  const u32x4* wp = reinterpret_cast<const u32x4*>(c->logits_w);
+  if (nrb == 4) hipLaunchKernelGGL((k_unembed<4>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
+  else if (nrb == 2) hipLaunchKernelGGL((k_unembed<2>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
+  else hipLaunchKernelGGL((k_unembed<1>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
+  timing_end(c, st, ti);
+  hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, nwaves, argmax_out);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -622,7 +636,7 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
 // The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
 // Logits are produced for rows [lrow0, lrow0+nl).  decode: one new token per row (rows never read each other's new K).
 // Launches per layer: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum + residual + norm),
-// dot_wi, swiglu, dot_wo, sumres, rownorm.
+// dot_wi, swiglu, dot_wo, rownorm (slice sum + residual + next norm).
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
@@ -630,6 +644,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
   DotResult dr;
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
+  const bool final_fused = nl == R && lrow0 == 0;   // decode: every row is unembedded
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
@@ -660,13 +675,19 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();
     TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
-    hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
-    LAUNCHCHK();
-    if (l + 1 < c->L) TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, c->layers[l + 1].ln1, c->xn, st));
+    // residual + the next norm (the next layer's pre-attention norm, or the final norm when every row gets logits) in one launch
+    if (l + 1 < c->L) {
+      TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, c->layers[l + 1].ln1, c->xn, st));
+    } else if (final_fused) {
+      TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, c->final_norm, c->xn, st));
+    } else {
+      hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
+      LAUNCHCHK();
+    }
   }
   if (nl > 0) {
     if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
-    TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st));
+    if (!final_fused) TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st));
     TRY(launch_unembed(c, c->xn, nl, logits_out, argmax_out, st));
   }
   return IXT_OK;

@@ -62,7 +62,7 @@ __host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xi
 
 // EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded to
 // bf16, optionally stored as f32 logits, and each wave emits its (max, first index) pair per row for k_argmax_final.
-//   grid = (ceil(waves/WPB), SPLIT ? chains : 1, ceil(rowblocks/NRB)), block = WPB waves (blockDim.x / 64), LDS = NRB x 16 KiB.
+//   grid = (ceil(waves/WPB) * ceil(rowblocks/NRB), SPLIT ? chains : 1), block = WPB waves (blockDim.x / 64), LDS = NRB x 16 KiB.
 //   A block = WPB adjacent 16-column tiles x one chain at a time x NRB 16-row blocks.  Per chain: every wave first issues the
 //   loads of its 16 weight fragments (16 x 1 KiB, all in flight together, HBM), then the block copies the chain's activation
 //   slab (NRB x 16 fragments, L2) into LDS once for all its waves, and each wave runs 16 x NRB MFMAs reading the activation
@@ -71,15 +71,16 @@ __host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xi
 template <int NRB, bool SPLIT, int EPI, bool NT>
 __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                  float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
-                                                 int nwaves, int TS) {
+                                                 int nwaves, int TS, int zblocks) {
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, nthr = blockDim.x, wpb = nthr >> 6;
   const int wave = tid >> 6, lane = tid & 63;
-  const int wid = blockIdx.x * wpb + wave;
+  // blockIdx.x = tile group * zblocks + row-block group: the blocks that stream the same weights are dispatched back to back
+  const int wid = ((int)blockIdx.x / zblocks) * wpb + wave;
   const int nsteps = K >> 5, ntile = N >> 4;
   const int nchains = (nsteps + 15) >> 4;
   const int nrbk = (R + 15) >> 4;
-  const int rb0 = blockIdx.z * NRB;
+  const int rb0 = ((int)blockIdx.x % zblocks) * NRB;
   const int c_begin = SPLIT ? (int)blockIdx.y : 0, c_end = SPLIT ? (int)blockIdx.y + 1 : nchains;
   const int r_in = lane & 15, cq = lane >> 4;
   float best[NRB];
@@ -201,6 +202,117 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
         amax_val[(size_t)row * nwaves + wid] = bv;
         amax_idx[(size_t)row * nwaves + wid] = bi;
       }
+    }
+  }
+}
+
+// =====================================================================================================
+// Unembedding + greedy sampling (decoders.py:566-587, inference_utils.py:74-75): the canonical dot over the [E][V] logits
+// kernel with the argmax epilogue, organised for a matrix that is far larger than any other (V = 264 192 columns):
+//   block = 4 waves x TS(4) tiles each = 256 adjacent columns, all chains, NRB 16-row blocks.
+//   chain-outer / tile-inner: the activation slab of a chain is copied to LDS ONCE per chain and reused for the block's 16
+//   (wave, tile) pairs; weight fragments stream through two 8-fragment register buffers, half a pair ahead of the MFMAs; the per-tile
+//   totals stay in registers across the chains (t = t + chain(c), c ascending: the canonical order).
+//   Each wave emits one (max, first index) pair per row over its 64 columns for k_argmax_final; logits (rounded to bf16,
+//   stored as f32) are written only when `out` is given.   grid = (ceil(V/256), 1, ceil(rowblocks/NRB)), block 256,
+//   LDS = NRB x 16 KiB.
+// =====================================================================================================
+template <int NRB>
+__global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+                                                    float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
+                                                    int nwaves) {
+  constexpr int TS = 4;
+  extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wid = blockIdx.x * 4 + wave;
+  const int nsteps = K >> 5, ntile = N >> 4;
+  const int nchains = (nsteps + 15) >> 4;
+  const int nrbk = (R + 15) >> 4;
+  const int rb0 = blockIdx.z * NRB;
+  const int r_in = lane & 15, cq = lane >> 4;
+  const int tile0 = wid * TS;
+  f32x4 tot[TS][NRB];
+#pragma unroll
+  for (int t = 0; t < TS; ++t)
+#pragma unroll
+    for (int b = 0; b < NRB; ++b) tot[t][b] = f32x4(0.0f);
+  u32x4 wa[8], wb[8];
+  // the 8 fragments of half H_ (steps 8 H_ .. 8 H_ + 7) of pair (chain C_, tile T_); a pair past the end loads nothing
+#define IXT_ULOADH(BUF_, C_, T_, H_)                                                                   \
+  do {                                                                                                 \
+    if ((C_) < nchains && tile0 + (T_) < ntile) {                                                      \
+      const u32x4* wp_ = wt + ((size_t)(tile0 + (T_)) * nsteps + (C_) * 16 + (H_) * 8) * 64 + lane;    \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                    \
+        if ((C_) * 16 + (H_) * 8 + s < nsteps) BUF_[s] = __builtin_nontemporal_load(wp_ + (size_t)s * 64); \
+    }                                                                                                  \
+  } while (0)
+#define IXT_UMMAH(BUF_, H_)                                                                            \
+  do {                                                                                                 \
+    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                    \
+      if ((H_) * 8 + s < cs) {                                                                         \
+        const bf16x8 wf_ = __builtin_bit_cast(bf16x8, BUF_[s]);                                        \
+        _Pragma("unroll") for (int b = 0; b < NRB; ++b)                                                \
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, __builtin_bit_cast(bf16x8, xs[b * 1024 + ((H_) * 8 + s) * 64 + lane]), acc[b], 0, 0, 0); \
+      }                                                                                                \
+    }                                                                                                  \
+  } while (0)
+  // pair (c, T_): first half from wa while wb fills with the second half, then the second half while wa fills with the first
+  // half of the NEXT pair (CN_, TN_): 8 fragment loads per wave stay in flight through the whole kernel
+#define IXT_UPAIR(T_, CN_, TN_)                                                                        \
+  do {                                                                                                 \
+    f32x4 acc[NRB];                                                                                    \
+    _Pragma("unroll") for (int b = 0; b < NRB; ++b) acc[b] = f32x4(0.0f);                              \
+    IXT_ULOADH(wb, c, T_, 1);                                                                          \
+    IXT_UMMAH(wa, 0);                                                                                  \
+    IXT_ULOADH(wa, CN_, TN_, 0);                                                                       \
+    IXT_UMMAH(wb, 1);                                                                                  \
+    _Pragma("unroll") for (int b = 0; b < NRB; ++b) tot[T_][b] = tot[T_][b] + acc[b];                  \
+  } while (0)
+  IXT_ULOADH(wa, 0, 0, 0);
+  for (int c = 0; c < nchains; ++c) {
+    const int s0 = c * 16;
+    const int cs = min(16, nsteps - s0);
+    if (c > 0) __syncthreads();                          // every wave is done with the previous slab
+    for (int e = tid; e < NRB * cs * 64; e += 256) {
+      const int b = e / (cs * 64), rem = e - b * (cs * 64);
+      xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0) * 64 + rem] : u32x4(0);
+    }
+    __syncthreads();
+    IXT_UPAIR(0, c, 1);
+    IXT_UPAIR(1, c, 2);
+    IXT_UPAIR(2, c, 3);
+    IXT_UPAIR(3, c + 1, 0);
+  }
+#undef IXT_ULOADH
+#undef IXT_UMMAH
+#undef IXT_UPAIR
+  if (wid >= nwaves) return;
+#pragma unroll
+  for (int b = 0; b < NRB; ++b) {
+    const int row = (rb0 + b) * 16 + r_in;
+    float bv = -INFINITY;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      if (tile0 + t < ntile) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = rbf(tot[t][b][j]);
+        if (out != nullptr && row < R) *reinterpret_cast<float4*>(out + (size_t)row * N + (tile0 + t) * 16 + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (v[j] > bv) { bv = v[j]; bi = (tile0 + t) * 16 + cq * 4 + j; }   // ascending columns: a later equal value never replaces
+      }
+    }
+#pragma unroll
+    for (int off = 16; off < 64; off <<= 1) {   // the 4 lanes of a row are lanes r, r+16, r+32, r+48
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if (cq == 0 && row < R) {
+      amax_val[(size_t)row * nwaves + wid] = bv;
+      amax_idx[(size_t)row * nwaves + wid] = bi;
     }
   }
 }
