@@ -5,7 +5,7 @@ configs[1], "C2"), data-parallel over N GPUs of one node (one process per GPU, n
   python bench.py --gpus N --steps K --warmup W
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 64) utterances per GPU,
+A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 256) utterances per GPU,
 each a 256-token prompt (4 s reference speech + 128-char text) prefilled into its slot, then
 `--decode-steps` (default 1024) greedy generate calls for all slots.  Tokens counted = generated audio tokens
 including the first one from prefill (decode.py:162-178: T-P generate calls yield T-P+1 tokens per utterance).
@@ -37,7 +37,7 @@ def parse():
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2)
   ap.add_argument("--warmup", type=int, default=1)
-  ap.add_argument("--batch", type=int, default=64, help="utterances (decode slots) per GPU")
+  ap.add_argument("--batch", type=int, default=256, help="utterances (decode slots) per GPU")
   ap.add_argument("--decode-steps", type=int, default=1024)
   ap.add_argument("--prefill-len", type=int, default=256)
   ap.add_argument("--model", default="indextts2-1b")
@@ -192,7 +192,9 @@ def main():
         "decode_mfu": step_flops / (ms_step * 1e-3) / MFMA_BF16_PEAK,
     }
 
-  # ---- roofline of the dominant kernel (k_dot: every weight byte of a decode step goes through it), measured live
+  # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (eager launches of 16 decode steps).
+  # Two kernel families carry (almost) every HBM byte of a decode step: the one-launch decode attention (K/V pages) and the
+  # canonical dot (weights).  The one with the larger share of the step is reported; the other rides along in "other".
   roofline = None
   if rank == 0 and not args.no_roofline:
     lib = eng.lib
@@ -204,20 +206,30 @@ def main():
     ds = eng.init_decode_state()
     for s in range(B):
       ds = eng.insert(prefixes[s], ds, s)
+    # advance to the middle of the decode range (graph replay), so that the measured contexts are the average ones
+    mid = max(0, args.decode_steps // 2 - 8)
+    for _ in range(mid):
+      ds, res = eng.generate(params, ds)
     torch.cuda.synchronize()
     lib.ixt_timing_enable(eng._ctx, 1)
     lib.ixt_timing_reset(eng._ctx)
-    for _ in range(16):
+    nmeas = 16
+    for _ in range(nmeas):
       ds, res = eng.generate(params, ds)
-    avg_us, n, bpl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-    lib.ixt_timing_get(eng._ctx, b"dot_decode", ctypes.byref(avg_us), ctypes.byref(n), ctypes.byref(bpl))
+
+    def fam(name):
+      avg_us, n, bpl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+      lib.ixt_timing_get(eng._ctx, name, ctypes.byref(avg_us), ctypes.byref(n), ctypes.byref(bpl))
+      return avg_us.value, int(n.value), bpl.value
+    dot_us, dot_n, dot_bpl = fam(b"dot_decode")
+    att_us, att_n, _ = fam(b"attn_decode")
     lib.ixt_timing_enable(eng._ctx, 0)
     for s in range(B):
       eng.release_pages(s)
-    achieved = bpl.value / (avg_us.value * 1e-6) / 1e9 if avg_us.value > 0 else 0.0
-    # flops of the same launches: 2 * rows * (weight elements); weight elements ~ (bytes - x - slices) / 2, dominated by the weights
-    w_elems = (nums["body_params"] + nums["unembed_params"]) / (4 * cfg.num_decoder_layers + 1)   # average per dot launch
-    tflops = 2.0 * B * w_elems / (avg_us.value * 1e-6) / 1e12 if avg_us.value > 0 else 0.0
+    # contexts during the measured steps: every utterance has true_length tl_s + mid + i + 1 keys at measured step i
+    ctx_sum = sum(tl + mid + (nmeas + 1) / 2.0 for (_, tl) in prompts)
+    kv_layer = nums["kv_bytes_per_token"] / cfg.num_decoder_layers                 # K+V bytes per token per layer (8 192 at C2)
+    att_bpl = ctx_sum * kv_layer + B * kv_layer                                    # read every cached key/value once + write the new one
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
     if os.path.exists(pmc):
@@ -227,12 +239,21 @@ def main():
           traffic, traffic_src = pj["hbm_bytes_per_launch"], pj.get("source")
       except Exception:  # pylint: disable=broad-except
         pass
-    kname = "k_dotb (canonical dot on v_mfma_f32_16x16x32_bf16)"
-    hbm_frac, mfma_frac = achieved / (HBM_PEAK / 1e9), tflops / (MFMA_BF16_PEAK / 1e12)
-    # bf16 matrix cores: 2.5 PFLOP/s dense; at <= 64 rows per weight stream the dot is bound by the weight bytes, not the matrix pipe
-    roofline = {"bound": "hbm", "kernel": kname + ", all launches of a decode step", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": hbm_frac, "mfma_bf16_TFLOPs": tflops, "mfma_bf16_frac": mfma_frac, "traffic": traffic, "traffic_source": traffic_src,
-                "avg_launch_us": avg_us.value, "launches": int(n.value), "algorithmic_bytes_per_launch": bpl.value}
+    dot = {"kernel": "k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
+           "achieved": dot_bpl / (dot_us * 1e-6) / 1e9 if dot_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": dot_us, "launches": dot_n,
+           "algorithmic_bytes_per_launch": dot_bpl, "us_per_step": dot_us * dot_n / nmeas}
+    att = {"kernel": "k_attn_decode (one launch per layer: QKV finalize, scores, softmax, PV over the paged KV cache)", "bound": "hbm",
+           "achieved": att_bpl / (att_us * 1e-6) / 1e9 if att_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": att_us, "launches": att_n,
+           "algorithmic_bytes_per_launch": att_bpl, "us_per_step": att_us * att_n / nmeas,
+           "mean_context": ctx_sum / B}
+    for d in (dot, att):
+      d["peak"] = HBM_PEAK / 1e9
+      d["frac"] = d["achieved"] / d["peak"]
+    main_k, other = (att, dot) if att["us_per_step"] >= dot["us_per_step"] else (dot, att)
+    roofline = dict(main_k)
+    roofline["traffic"] = traffic
+    roofline["traffic_source"] = traffic_src
+    roofline["other"] = other
 
   # ---- CPU baseline: the oracle (a port restating the reference algorithm) on a bounded sample, rank 0, N=1 only
   cpu_baseline = None

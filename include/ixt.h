@@ -143,7 +143,8 @@ int ixt_rope_tables(ixt_ctx* ctx, uint16_t* sin_out, uint16_t* cos_out);
 
 /* Live measurement hook for bench.py: average duration in microseconds of the named kernel family over the
  * launches made by this ctx since the last ixt_timing_reset, measured with HIP events on the launch stream.
- * Families: "dot_decode". Returns negative if timing is disabled. */
+ * Families: "dot_decode" (canonical dot launches, bytes priced by the library), "attn_decode" (one-launch decode attention;
+ * bytes_per_launch is 0: the K/V bytes depend on the rows' lengths, the caller prices them). */
 int ixt_timing_enable(ixt_ctx* ctx, int enable);
 int ixt_timing_reset(ixt_ctx* ctx);
 int ixt_timing_get(ixt_ctx* ctx, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch);

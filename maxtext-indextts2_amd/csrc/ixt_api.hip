@@ -37,7 +37,7 @@ struct LayerW {
 
 enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER };
 
-struct TimingPair { hipEvent_t a, b; double bytes; };
+struct TimingPair { hipEvent_t a, b; double bytes; int family; };   // family: 0 canonical dot (incl. unembedding), 1 one-launch decode attention
 
 struct GraphEntry {
   hipGraphExec_t exec;
@@ -385,7 +385,7 @@ extern "C" int ixt_pages_import_status(ixt_ctx* c, const int32_t* page_status, v
 }
 
 // --------------------------------------------------------------------------------------- launches
-static int timing_begin(ixt_ctx* c, hipStream_t st, double bytes) {
+static int timing_begin(ixt_ctx* c, hipStream_t st, double bytes, int family = 0) {
   if (!c->timing || c->capturing) return -1;
   if (c->tused == c->tpairs.size()) {
     if (c->tpairs.size() >= 16384) return -1;
@@ -395,6 +395,7 @@ static int timing_begin(ixt_ctx* c, hipStream_t st, double bytes) {
   }
   TimingPair& t = c->tpairs[c->tused];
   t.bytes = bytes;
+  t.family = family;
   (void)hipEventRecord(t.a, st);
   return (int)c->tused++;
 }
@@ -443,7 +444,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
   const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
   {
-    dim3 grid(((nwaves + wpb - 1) / wpb) * zblocks, split ? chains : 1, 1);
+    dim3 grid((((nwaves + wpb - 1) / wpb + 7) / 8) * 8 * zblocks, split ? chains : 1, 1);   // tile groups padded to the 8 XCDs
     const dim3 block(64 * wpb);
     const size_t lds = (size_t)nrb * 16 * 1024;
     const u32x4* xp = reinterpret_cast<const u32x4*>(x);
@@ -475,16 +476,19 @@ static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out
   const int rowblocks = (R + 15) / 16;
   const int nrb = rowblocks >= 3 ? 4 : rowblocks;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
-  if (zblocks != 1) return set_err(IXT_ERR_UNSUPPORTED, "unembedding of more than 64 rows in one call");
   if ((size_t)R * nwaves > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
   const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (logits_out ? (double)R * N * 4.0 : 0.0));
-  dim3 grid((nwaves + 3) / 4, 1, zblocks);
+  dim3 grid((((nwaves + 3) / 4 + 7) / 8) * 8 * zblocks, 1, 1);   // column groups padded to the 8 XCDs
   const size_t lds = (size_t)nrb * 16 * 1024;
   const u32x4* xp = reinterpret_cast<const u32x4*>(yT);
   const u32x4* wp = reinterpret_cast<const u32x4*>(c->logits_w);
-  if (nrb == 4) hipLaunchKernelGGL((k_unembed<4>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
-  else if (nrb == 2) hipLaunchKernelGGL((k_unembed<2>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
-  else hipLaunchKernelGGL((k_unembed<1>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves);
+#define UNEMB(B_)                                                                                                                          \
+  do {                                                                                                                                     \
+    if (zblocks == 1) hipLaunchKernelGGL((k_unembed<B_, true>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks); \
+    else hipLaunchKernelGGL((k_unembed<B_, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks);           \
+  } while (0)
+  if (nrb == 4) UNEMB(4); else if (nrb == 2) UNEMB(2); else UNEMB(1);
+#undef UNEMB
   timing_end(c, st, ti);
   hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, nwaves, argmax_out);
   LAUNCHCHK();
@@ -663,7 +667,9 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     const int fused_min = c->attn_fused_min_blocks;
     const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * c->geom.Tmax + c->geom.mpg + 8 + (size_t)c->geom.nsb_max * c->D);
     if (decode && R * c->KV >= fused_min && fused_lds <= 64 * 1024) {
+      const int ta = timing_begin(c, st, 0.0, 1);   // K/V bytes depend on the rows' lengths: the caller prices them
       TRY(launch_attention_fused(c, l, R, dr, st));
+      timing_end(c, st, ta);
     } else {
       TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));
       hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
@@ -898,18 +904,24 @@ extern "C" int ixt_timing_reset(ixt_ctx* c) {
 }
 extern "C" int ixt_timing_get(ixt_ctx* c, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch) {
   if (!c || !family) return set_err(IXT_ERR_INVALID, "null argument");
-  if (strcmp(family, "dot") != 0 && strcmp(family, "dot_decode") != 0) return set_err(IXT_ERR_INVALID, "unknown family %s", family);
+  int fam;
+  if (strcmp(family, "dot") == 0 || strcmp(family, "dot_decode") == 0) fam = 0;
+  else if (strcmp(family, "attn_decode") == 0) fam = 1;
+  else return set_err(IXT_ERR_INVALID, "unknown family %s", family);
   HIPCHK(hipDeviceSynchronize());
   double tot_ms = 0.0, tot_bytes = 0.0;
+  size_t cnt = 0;
   for (size_t i = 0; i < c->tused; ++i) {
+    if (c->tpairs[i].family != fam) continue;
     float ms = 0.0f;
     HIPCHK(hipEventElapsedTime(&ms, c->tpairs[i].a, c->tpairs[i].b));
     tot_ms += ms;
     tot_bytes += c->tpairs[i].bytes;
+    ++cnt;
   }
-  const double n = c->tused ? (double)c->tused : 1.0;
+  const double n = cnt ? (double)cnt : 1.0;
   if (avg_us) *avg_us = tot_ms * 1000.0 / n;
-  if (launches) *launches = (int64_t)c->tused;
+  if (launches) *launches = (int64_t)cnt;
   if (bytes_per_launch) *bytes_per_launch = tot_bytes / n;
   return IXT_OK;
 }

@@ -75,12 +75,14 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, nthr = blockDim.x, wpb = nthr >> 6;
   const int wave = tid >> 6, lane = tid & 63;
-  // blockIdx.x = tile group * zblocks + row-block group: the blocks that stream the same weights are dispatched back to back
-  const int wid = ((int)blockIdx.x / zblocks) * wpb + wave;
+  // Blocks that stream the same weights (the row-block groups of one tile group) must share an L2: consecutive block ids are
+  // dealt round-robin over the 8 XCDs, so the row-block group is taken from (blockIdx.x / 8) and ids b, b + 8, .. are partners.
+  const int bx = blockIdx.x;
+  const int wid = ((bx / (8 * zblocks)) * 8 + (bx & 7)) * wpb + wave;
   const int nsteps = K >> 5, ntile = N >> 4;
   const int nchains = (nsteps + 15) >> 4;
   const int nrbk = (R + 15) >> 4;
-  const int rb0 = ((int)blockIdx.x % zblocks) * NRB;
+  const int rb0 = ((bx >> 3) % zblocks) * NRB;
   const int c_begin = SPLIT ? (int)blockIdx.y : 0, c_end = SPLIT ? (int)blockIdx.y + 1 : nchains;
   const int r_in = lane & 15, cq = lane >> 4;
   float best[NRB];
@@ -214,21 +216,22 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
 //   (wave, tile) pairs; weight fragments stream through two 8-fragment register buffers, half a pair ahead of the MFMAs; the per-tile
 //   totals stay in registers across the chains (t = t + chain(c), c ascending: the canonical order).
 //   Each wave emits one (max, first index) pair per row over its 64 columns for k_argmax_final; logits (rounded to bf16,
-//   stored as f32) are written only when `out` is given.   grid = (ceil(V/256), 1, ceil(rowblocks/NRB)), block 256,
+//   stored as f32) are written only when `out` is given.   grid = ceil(V/256) * ceil(rowblocks/NRB), block 256,
 //   LDS = NRB x 16 KiB.
 // =====================================================================================================
-template <int NRB>
+template <int NRB, bool NT>
 __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                     float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
-                                                    int nwaves) {
+                                                    int nwaves, int zblocks) {
   constexpr int TS = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wid = blockIdx.x * 4 + wave;
+  const int bx = blockIdx.x;                                   // partners (same columns, other rows) are ids b, b + 8, ..: same XCD, same L2
+  const int wid = ((bx / (8 * zblocks)) * 8 + (bx & 7)) * 4 + wave;
   const int nsteps = K >> 5, ntile = N >> 4;
   const int nchains = (nsteps + 15) >> 4;
   const int nrbk = (R + 15) >> 4;
-  const int rb0 = blockIdx.z * NRB;
+  const int rb0 = ((bx >> 3) % zblocks) * NRB;
   const int r_in = lane & 15, cq = lane >> 4;
   const int tile0 = wid * TS;
   f32x4 tot[TS][NRB];
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
     if ((C_) < nchains && tile0 + (T_) < ntile) {                                                      \
       const u32x4* wp_ = wt + ((size_t)(tile0 + (T_)) * nsteps + (C_) * 16 + (H_) * 8) * 64 + lane;    \
       _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                    \
-        if ((C_) * 16 + (H_) * 8 + s < nsteps) BUF_[s] = __builtin_nontemporal_load(wp_ + (size_t)s * 64); \
+        if ((C_) * 16 + (H_) * 8 + s < nsteps) { if constexpr (NT) BUF_[s] = __builtin_nontemporal_load(wp_ + (size_t)s * 64); else BUF_[s] = wp_[(size_t)s * 64]; } \
     }                                                                                                  \
   } while (0)
 #define IXT_UMMAH(BUF_, H_)                                                                            \
@@ -1012,8 +1015,64 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
   constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
   const int tq = lane / LPP, dc = lane % LPP;
+  // PV work of this wave as a flat list of batches: group i = pages pg0 = (wave + 4 i) PPW .. + PPW - 1 (lane: page pg0 + tq,
+  // d-chunk dc), batch bt = tokens 8 bt .. 8 bt + 7 of the lane's page.  The loads of batch f + 1 are issued before the fma
+  // chains of batch f, and batch 0 before the softmax of the head: V does not depend on it.
+  const int nb = g.P / 8;                                              // batches per page
+  const int ngrp = (pages > wave * PPW) ? (pages - wave * PPW + 4 * PPW - 1) / (4 * PPW) : 0;
+  const int nf = ngrp * nb;
+#define IXT_VLOAD(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    if (f_ < nf) {                                                                                                \
+      const int p_ = (wave + 4 * (f_ / nb)) * PPW + tq, t0_ = (f_ % nb) * 8;                                      \
+      if (p_ < pages) {                                                                                           \
+        const bf16_t* vp_ = a.vpages + vpage_off(g, prow[p_], kvh, t0_) + dc * 8;                                 \
+        const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                             \
+          if (u < nt_) BUF_[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)u * HD);                           \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+#define IXT_VBATCH(BUF_, F_)                                                                                      \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    const int pg0_ = (wave + 4 * (f_ / nb)) * PPW, p_ = pg0_ + tq, bt_ = f_ % nb, t0_ = bt_ * 8;                  \
+    if (bt_ == 0) { _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = 0.0f; }                                \
+    if (p_ < pages) {                                                                                             \
+      const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                          \
+      const float* pj_ = e + (size_t)p_ * g.P + t0_;                                                              \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                             \
+        if (u < nt_) {                                                                                            \
+          float vf[8] = {bflo(BUF_[u].x), bfhi(BUF_[u].x), bflo(BUF_[u].y), bfhi(BUF_[u].y),                      \
+                         bflo(BUF_[u].z), bfhi(BUF_[u].z), bflo(BUF_[u].w), bfhi(BUF_[u].w)};                     \
+          if (p_ * g.P + t0_ + u == pos) {   /* the token this block has just written: its value comes from LDS */ \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) vf[j] = vn[dc * 8 + j];                                 \
+          }                                                                                                       \
+          const float pv = pj_[u];                                                                                \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);               \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (bt_ == nb - 1) {   /* group complete: super-block sums (pages 4s..4s+3 live in lane groups tq = 4s..4s+3) */ \
+      const int sbl = tq / IXT_SB, base_lane = sbl * IXT_SB * LPP + dc;                                           \
+      float ss[8];                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = 0.0f;                                                 \
+      _Pragma("unroll") for (int i = 0; i < IXT_SB; ++i) {                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = ss[j] + __shfl(acc[j], base_lane + i * LPP, 64);    \
+      }                                                                                                           \
+      const int sb = pg0_ / IXT_SB + sbl;                                                                         \
+      if (tq % IXT_SB == 0 && sb < nsb) {                                                                         \
+        float* dst = sbs + (size_t)sb * HD + dc * 8;                                                              \
+        *reinterpret_cast<float4*>(dst) = make_float4(ss[0], ss[1], ss[2], ss[3]);                                \
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(ss[4], ss[5], ss[6], ss[7]);                            \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
   for (int q = 0; q < GQ; ++q) {
     float* e = ebuf + (size_t)q * g.Tmax;
+    u32x4 va[8], vb[8];
+    IXT_VLOAD(va, 0);
     // max (order independent), exp, page sums in key order, l in page order, P
     float m = -INFINITY;
     for (int j = tid; j < kv_len; j += 256) m = fmaxf(m, e[j]);
@@ -1035,51 +1094,13 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     for (int p = 0; p < pages; ++p) l = l + psum[p];
     for (int j = tid; j < kv_len; j += 256) e[j] = rbf(e[j] / l);
     __syncthreads();
-    // PV: one wave-iteration = PPW pages = PPW/4 super-blocks
-    for (int pg0 = wave * PPW; pg0 < pages; pg0 += 4 * PPW) {
-      const int p = pg0 + tq;
-      float acc[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
-      if (p < pages) {
-        const bf16_t* vp = a.vpages + vpage_off(g, prow[p], kvh, 0) + dc * 8;
-        const int ntok = min(g.P, kv_len - p * g.P);
-        const float* pj = e + (size_t)p * g.P;
-        for (int t0 = 0; t0 < ntok; t0 += 8) {
-          u32x4 vv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u)
-            vv[u] = (t0 + u < ntok) ? *reinterpret_cast<const u32x4*>(vp + (size_t)(t0 + u) * HD) : u32x4(0);
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            if (t0 + u < ntok) {
-              float vf[8] = {bflo(vv[u].x), bfhi(vv[u].x), bflo(vv[u].y), bfhi(vv[u].y), bflo(vv[u].z), bfhi(vv[u].z), bflo(vv[u].w), bfhi(vv[u].w)};
-              if (p * g.P + t0 + u == pos) {   // the token this block has just written: its value comes from LDS
-#pragma unroll
-                for (int j = 0; j < 8; ++j) vf[j] = vn[dc * 8 + j];
-              }
-              const float pv = pj[t0 + u];
-#pragma unroll
-              for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);
-            }
-          }
-        }
-      }
-      const int sbl = tq / IXT_SB;            // super-block within the wave-iteration
-      const int base_lane = sbl * IXT_SB * LPP + dc;
-      float ss[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ss[j] = 0.0f;
-#pragma unroll
-      for (int i = 0; i < IXT_SB; ++i) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) ss[j] = ss[j] + __shfl(acc[j], base_lane + i * LPP, 64);
-      }
-      const int sb = pg0 / IXT_SB + sbl;
-      if (tq % IXT_SB == 0 && sb < nsb) {
-        float* dst = sbs + (size_t)sb * HD + dc * 8;
-        *reinterpret_cast<float4*>(dst) = make_float4(ss[0], ss[1], ss[2], ss[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(ss[4], ss[5], ss[6], ss[7]);
+    float acc[8];
+    for (int f = 0; f < nf; f += 2) {
+      IXT_VLOAD(vb, f + 1);
+      IXT_VBATCH(va, f);
+      if (f + 1 < nf) {
+        IXT_VLOAD(va, f + 2);
+        IXT_VBATCH(vb, f + 1);
       }
     }
     __syncthreads();
@@ -1090,6 +1111,8 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     }
     __syncthreads();
   }
+#undef IXT_VLOAD
+#undef IXT_VBATCH
 }
 
 // ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
