@@ -128,6 +128,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!is_pow2(c.pagedattn_tokens_per_page) || c.pagedattn_tokens_per_page < 8 || c.pagedattn_tokens_per_page > 64)
     return set_err(IXT_ERR_UNSUPPORTED, "pagedattn_tokens_per_page must be a power of two in [8, 64]");
   if (c.vocab_size % 16) return set_err(IXT_ERR_UNSUPPORTED, "vocab_size must be a multiple of 16");
+  if (c.max_slots > IXT_MAX_GROUPS || c.pagedattn_max_pages_per_group > IXT_MAX_GROUPS)
+    return set_err(IXT_ERR_UNSUPPORTED, "more than %d slots or pages per group", IXT_MAX_GROUPS);
   // page_manager.py:450-473
   if (c.pagedattn_max_pages_per_group <= 0) return set_err(IXT_ERR_INVALID, "`pagedattn_max_pages_per_group` must be positive.");
   if (c.pagedattn_max_pages_per_group < (c.max_target_length + c.pagedattn_tokens_per_page - 1) / c.pagedattn_tokens_per_page)

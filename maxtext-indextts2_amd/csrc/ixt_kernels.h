@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
 // kernel with the argmax epilogue, organised for a matrix that is far larger than any other (V = 264 192 columns):
 //   block = 4 waves x TS(4) tiles each = 256 adjacent columns, all chains, NRB 16-row blocks.
 //   chain-outer / tile-inner: the activation slab of a chain is copied to LDS ONCE per chain and reused for the block's 16
-//   (wave, tile) pairs; weight fragments stream through two 8-fragment register buffers, half a pair ahead of the MFMAs; the per-tile
+//   (wave, tile) pairs; weight fragments stream through two 8-fragment register buffers, a quarter chain ahead of the MFMAs; the per-tile
 //   totals stay in registers across the chains (t = t + chain(c), c ascending: the canonical order).
 //   Each wave emits one (max, first index) pair per row over its 64 columns for k_argmax_final; logits (rounded to bf16,
 //   stored as f32) are written only when `out` is given.   grid = ceil(V/256) * ceil(rowblocks/NRB), block 256,
@@ -240,38 +240,51 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
 #pragma unroll
     for (int b = 0; b < NRB; ++b) tot[t][b] = f32x4(0.0f);
   u32x4 wa[8], wb[8];
-  // the 8 fragments of half H_ (steps 8 H_ .. 8 H_ + 7) of pair (chain C_, tile T_); a pair past the end loads nothing
-#define IXT_ULOADH(BUF_, C_, T_, H_)                                                                   \
+  // A wave runs its 4 tiles as 2 duos: both tiles of a duo consume the SAME activation fragments, read from LDS once per
+  // step (the LDS port, shared by the 4 SIMDs, is the scarce resource here: one 1 KiB read per MFMA would saturate it).
+  // quarter Q_ (steps 4 Q_ .. 4 Q_ + 3) of duo D_ in chain C_: 2 tiles x 4 fragments; a tile past the end loads nothing
+#define IXT_ULOADQ(BUF_, C_, D_, Q_)                                                                   \
   do {                                                                                                 \
-    if ((C_) < nchains && tile0 + (T_) < ntile) {                                                      \
-      const u32x4* wp_ = wt + ((size_t)(tile0 + (T_)) * nsteps + (C_) * 16 + (H_) * 8) * 64 + lane;    \
-      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                    \
-        if ((C_) * 16 + (H_) * 8 + s < nsteps) { if constexpr (NT) BUF_[s] = __builtin_nontemporal_load(wp_ + (size_t)s * 64); else BUF_[s] = wp_[(size_t)s * 64]; } \
-    }                                                                                                  \
-  } while (0)
-#define IXT_UMMAH(BUF_, H_)                                                                            \
-  do {                                                                                                 \
-    _Pragma("unroll") for (int s = 0; s < 8; ++s) {                                                    \
-      if ((H_) * 8 + s < cs) {                                                                         \
-        const bf16x8 wf_ = __builtin_bit_cast(bf16x8, BUF_[s]);                                        \
-        _Pragma("unroll") for (int b = 0; b < NRB; ++b)                                                \
-          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, __builtin_bit_cast(bf16x8, xs[b * 1024 + ((H_) * 8 + s) * 64 + lane]), acc[b], 0, 0, 0); \
+    if ((C_) * 16 + (Q_) * 4 < nsteps) {   /* feature sizes are multiples of 128: a quarter is whole or absent */ \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                  \
+        const int tl_ = min(tile0 + (D_) * 2 + u, ntile - 1);   /* past the end: a valid tile, result dropped */ \
+        const u32x4* wp_ = wt + ((size_t)tl_ * nsteps + (C_) * 16 + (Q_) * 4) * 64 + lane;             \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+          if constexpr (NT) BUF_[u * 4 + s] = __builtin_nontemporal_load(wp_ + (size_t)s * 64);        \
+          else BUF_[u * 4 + s] = wp_[(size_t)s * 64];                                                  \
+        }                                                                                              \
       }                                                                                                \
     }                                                                                                  \
   } while (0)
-  // pair (c, T_): first half from wa while wb fills with the second half, then the second half while wa fills with the first
-  // half of the NEXT pair (CN_, TN_): 8 fragment loads per wave stay in flight through the whole kernel
-#define IXT_UPAIR(T_, CN_, TN_)                                                                        \
+#define IXT_UMMAQ(BUF_, Q_)                                                                            \
   do {                                                                                                 \
-    f32x4 acc[NRB];                                                                                    \
-    _Pragma("unroll") for (int b = 0; b < NRB; ++b) acc[b] = f32x4(0.0f);                              \
-    IXT_ULOADH(wb, c, T_, 1);                                                                          \
-    IXT_UMMAH(wa, 0);                                                                                  \
-    IXT_ULOADH(wa, CN_, TN_, 0);                                                                       \
-    IXT_UMMAH(wb, 1);                                                                                  \
-    _Pragma("unroll") for (int b = 0; b < NRB; ++b) tot[T_][b] = tot[T_][b] + acc[b];                  \
+    if ((Q_) * 4 < cs) {                                                                               \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                  \
+        bf16x8 xf_[NRB];                                                                               \
+        _Pragma("unroll") for (int b = 0; b < NRB; ++b) xf_[b] = __builtin_bit_cast(bf16x8, xs[b * 1024 + ((Q_) * 4 + s) * 64 + lane]); \
+        _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                \
+          const bf16x8 wf_ = __builtin_bit_cast(bf16x8, BUF_[u * 4 + s]);                              \
+          _Pragma("unroll") for (int b = 0; b < NRB; ++b)                                              \
+            acc[u][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_, xf_[b], acc[u][b], 0, 0, 0);      \
+        }                                                                                              \
+      }                                                                                                \
+    }                                                                                                  \
   } while (0)
-  IXT_ULOADH(wa, 0, 0, 0);
+  // duo D_ of chain c: quarters alternate between the two buffers; the next quarter (of this duo, of the next duo, or of the
+  // next chain's first duo: (CN_, DN_)) is always in flight while the current one runs
+#define IXT_UDUO(D_, CN_, DN_)                                                                         \
+  do {                                                                                                 \
+    f32x4 acc[2][NRB];                                                                                 \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int b = 0; b < NRB; ++b) acc[u][b] = f32x4(0.0f);                         \
+    IXT_ULOADQ(wb, c, D_, 1); IXT_UMMAQ(wa, 0);                                                        \
+    IXT_ULOADQ(wa, c, D_, 2); IXT_UMMAQ(wb, 1);                                                        \
+    IXT_ULOADQ(wb, c, D_, 3); IXT_UMMAQ(wa, 2);                                                        \
+    IXT_ULOADQ(wa, CN_, DN_, 0); IXT_UMMAQ(wb, 3);                                                     \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                                      \
+      _Pragma("unroll") for (int b = 0; b < NRB; ++b) tot[(D_) * 2 + u][b] = tot[(D_) * 2 + u][b] + acc[u][b]; \
+  } while (0)
+  IXT_ULOADQ(wa, 0, 0, 0);
   for (int c = 0; c < nchains; ++c) {
     const int s0 = c * 16;
     const int cs = min(16, nsteps - s0);
@@ -281,14 +294,12 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
       xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0) * 64 + rem] : u32x4(0);
     }
     __syncthreads();
-    IXT_UPAIR(0, c, 1);
-    IXT_UPAIR(1, c, 2);
-    IXT_UPAIR(2, c, 3);
-    IXT_UPAIR(3, c + 1, 0);
+    IXT_UDUO(0, c, 1);
+    IXT_UDUO(1, c + 1, 0);
   }
-#undef IXT_ULOADH
-#undef IXT_UMMAH
-#undef IXT_UPAIR
+#undef IXT_ULOADQ
+#undef IXT_UMMAQ
+#undef IXT_UDUO
   if (wid >= nwaves) return;
 #pragma unroll
   for (int b = 0; b < NRB; ++b) {
@@ -1262,35 +1273,83 @@ __global__ __launch_bounds__(64) void k_pages_reset(PageStateDev s) {
 }
 __global__ __launch_bounds__(64) void k_pages_release(PageStateDev s, int g) { wave_release_group(s, g, threadIdx.x); }
 
+// The m lowest free pages (index >= 1) in ascending order -> out[0..m) (LDS), each marked used; returns how many exist (<= m).
+// Sequential first-fit (page_manager.py:268-283, :373-395: "next free page" for one request after the other, nothing freed in
+// between) hands out exactly these pages in exactly this order, so one scan serves a whole batch of requests.
+// Plain loads: within one launch every status word is read before this wave may write it.
+__device__ int wave_take_free(int32_t* status, int num_pages, int lane, int m, int32_t* out) {
+  int cnt = 0;
+  for (int base = 0; base < num_pages && cnt < m; base += 512) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 64 + lane;
+      v[u] = (i >= 1 && i < num_pages) ? status[i] : 1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 64 + lane;
+      const bool free_ = v[u] == 0;
+      const unsigned long long mask = __ballot(free_);
+      if (free_) {
+        const int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        if (rank < m) { out[rank] = i; status[i] = 1; }
+      }
+      cnt += __popcll(mask);
+    }
+  }
+  return cnt < m ? cnt : m;
+}
+__device__ int wave_count_free8(const int32_t* status, int num_pages, int lane) {
+  int c = 0;
+  for (int base = 0; base < num_pages; base += 512) {
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = base + u * 64 + lane;
+      v[u] = i < num_pages ? status[i] : 1;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c += __popcll(__ballot(v[u] == 0));
+  }
+  return c;
+}
+#define IXT_MAX_GROUPS 4096
+
 // release + reserve (page_manager.py:208-328); extend != 0: keep pages, grow to `length` tokens (build extension)
 __global__ __launch_bounds__(64) void k_pages_reserve(PageStateDev s, int g, int length, int extend) {
+  __shared__ int32_t got[IXT_MAX_GROUPS];
   const int lane = threadIdx.x;
-  if (!extend) wave_release_group(s, g, lane);
+  if (!extend) {
+    wave_release_group(s, g, lane);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");   // the freed status words (L1-bypassing stores) before the plain scans below
+  }
+  __syncthreads();
   const int need = (length + s.P - 1) / s.P;
   const int have = extend ? ldg_i32(s.num_pages_used + g) : 0;
   const int extra = need > have ? need - have : 0;
-  const int nfree = wave_count_free(s.page_status, s.num_pages, lane);
+  const int nfree = wave_count_free8(s.page_status, s.num_pages, lane);
   if (!(nfree >= extra && need <= s.mpg)) return;
-  for (int i = have; i < need; ++i) {
-    const int nf = wave_find_free(s.page_status, s.num_pages, lane);
-    if (nf >= 0 && lane == 0) {
-      stg_i32(s.page_status + nf, 1);
-      stg_i32(s.page_map + (size_t)g * s.mpg + i, nf);
-      stg_i32(s.num_pages_used + g, ldg_i32(s.num_pages_used + g) + 1);
-    }
-    wave_drain();
-  }
+  const int found = wave_take_free(s.page_status, s.num_pages, lane, extra, got);
+  __syncthreads();
+  for (int k = lane; k < found; k += 64) s.page_map[(size_t)g * s.mpg + have + k] = got[k];
+  __syncthreads();
   if (lane == 0) {
-    stg_i32(s.sequence_lengths + g, length);
-    stg_i32(s.active_page + g, ldg_i32(s.page_map + (size_t)g * s.mpg + need - 1));
-    stg_i32(s.has_active_page + g, 1);
-    stg_i32(s.active_page_position + g, ((length - 1) % s.P + 1) % s.P);
+    s.num_pages_used[g] = have + found;
+    s.sequence_lengths[g] = length;
+    s.active_page[g] = (need - 1 < have) ? s.page_map[(size_t)g * s.mpg + need - 1] : got[need - 1 - have];
+    s.has_active_page[g] = 1;
+    s.active_page_position[g] = ((length - 1) % s.P + 1) % s.P;
   }
 }
 
-// page_manager.py:331-412
+// page_manager.py:331-412: every active group advances one token; groups that cross a page boundary take the next free page,
+// in group order
 __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
+  __shared__ int32_t need[IXT_MAX_GROUPS];
+  __shared__ int32_t got[IXT_MAX_GROUPS];
   const int lane = threadIdx.x;
+  int m = 0;
   for (int base = 0; base < s.groups; base += 64) {
     const int g = base + lane;
     bool needs = false;
@@ -1302,21 +1361,20 @@ __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
       const int required = (nl + s.P - 1) / s.P;
       needs = act && required > s.num_pages_used[g] && required <= s.mpg;
     }
-    unsigned long long mask = __ballot(needs);
-    while (mask) {
-      const int gl = __ffsll((long long)mask) - 1;
-      mask &= mask - 1;
-      const int gg = base + gl;
-      const int nf = wave_find_free(s.page_status, s.num_pages, lane);
-      if (nf >= 0 && lane == 0) {
-        stg_i32(s.page_status + nf, 1);
-        const int used = s.num_pages_used[gg];
-        s.page_map[(size_t)gg * s.mpg + used] = nf;
-        s.num_pages_used[gg] = used + 1;
-        s.active_page[gg] = nf;
-      }
-      wave_drain();
-    }
+    const unsigned long long mask = __ballot(needs);
+    if (needs) need[m + __popcll(mask & ((1ull << lane) - 1ull))] = g;
+    m += __popcll(mask);
+  }
+  if (m == 0) return;
+  __syncthreads();
+  const int found = wave_take_free(s.page_status, s.num_pages, lane, m, got);
+  __syncthreads();
+  for (int k = lane; k < found; k += 64) {
+    const int gg = need[k], nf = got[k];
+    const int used = s.num_pages_used[gg];
+    s.page_map[(size_t)gg * s.mpg + used] = nf;
+    s.num_pages_used[gg] = used + 1;
+    s.active_page[gg] = nf;
   }
 }
 __global__ void k_pages_set_active(PageStateDev s, int g, int v) { s.has_active_page[g] = v; }
