@@ -67,7 +67,8 @@ int ixt_destroy(ixt_ctx* ctx);
  * both spellings of the MLP pre-norm are accepted ("mlp/mlp_layer_norm/scale" of linears.py:347-354 and
  * "post_self_attention_layer_norm/scale" of llama_or_mistral_ckpt.py:449-450).  `dev_ptr` is a device
  * pointer to a dense row-major array of `shape[ndim]`; IXT_F32 sources are rounded to bf16
- * (round-to-nearest-even) as linears.py:216 / embeddings.py:154 do at use. */
+ * (round-to-nearest-even) as linears.py:216 / embeddings.py:154 do at use.  Projection kernels are re-tiled into the
+ * matrix-fragment order of the GEMM kernels while they are copied (the caller's array is not kept). */
 int ixt_load_weight(ixt_ctx* ctx, const char* maxtext_path, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, void* stream);
 /* 1 when every parameter of the configured model has been loaded. */
 int ixt_weights_complete(ixt_ctx* ctx);
@@ -117,7 +118,8 @@ int ixt_generate(ixt_ctx* ctx, int32_t* tokens_dev, int32_t* next_pos_dev, int32
                  int32_t* result_data_dev, float* logits_dev, void* stream);
 
 /* ---- op-level entry points (unit parity against the oracle) ---------------------------------------- */
-/* DenseGeneral.__call__ (linears.py:188-232) in canonical order: out f32[R*N] = x bf16[R*K] . W bf16[K*N]. */
+/* DenseGeneral.__call__ (linears.py:188-232) in canonical order: out f32[R*N] = x bf16[R*K] . W bf16[K*N] (both row-major;
+ * K % 32 == 0, N % 16 == 0; W is re-tiled into a scratch copy first). */
 int ixt_op_dot(ixt_ctx* ctx, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream);
 /* RMSNorm.__call__ (normalizations.py:57-70): out bf16[R*E]. */
 int ixt_op_rmsnorm(ixt_ctx* ctx, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream);

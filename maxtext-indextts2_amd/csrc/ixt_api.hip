@@ -413,31 +413,26 @@ static int env_int(const char* name, int dflt) {
 }
 
 // x: bf16 in the dot x layout (xidx); w: bf16 in the tiled weight layout (widx).  out: f32 [slices][R][N]; force_full: one
-// slice (all chains added inside the wave).  epi_argmax: greedy-sampling epilogue (one slice; `out` may be null = do not store
-// logits; (max,idx) pairs -> c->amax_*).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per wave).
+// slice (all chains added inside the wave).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per block);
+// more rows run as partner blocks on the same XCD.
 static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
-                      bool force_full, hipStream_t st, DotResult* res, bool epi_argmax = false) {
+                      bool force_full, hipStream_t st, DotResult* res) {
   if (K % IXT_MK || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 32 or N %% 16");
-  if (out == nullptr && !epi_argmax) return set_err(IXT_ERR_INVALID, "dot: null output");
+  if (out == nullptr) return set_err(IXT_ERR_INVALID, "dot: null output");
   const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
   const int ntile = N / 16;
   const int rowblocks = (R + 15) / 16;
   static const int nrb_env = env_int("IXT_DOT_NRB", 0);
-  static const int ts_env = env_int("IXT_DOT_EPI_TS", 4);
   static const int wpb_env = env_int("IXT_DOT_WPB", 0);
   int nrb = rowblocks >= 3 ? 4 : rowblocks;
   if (nrb_env == 1 || nrb_env == 2 || nrb_env == 4) nrb = nrb_env;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
-  bool split = !force_full && !epi_argmax && chains > 1;
+  bool split = !force_full && chains > 1;
+  // (letting a block walk its chains itself at many rows -- one slice instead of `chains` -- was measured: 102 vs 54 us on the
+  //  2048 x 14336 kernel at 256 rows; the per-chain barriers and slab copies cost more than the slices)
   if (split && (size_t)chains * R * N > out_floats) split = false;
-  if (!split && out != nullptr && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
-  const int TS = epi_argmax ? (ts_env > 0 ? ts_env : 1) : 1;
-  const int nwaves = (ntile + TS - 1) / TS;
-  float* av = nullptr; int32_t* ai = nullptr;
-  if (epi_argmax) {
-    if ((size_t)R * nwaves > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
-    av = c->amax_val; ai = c->amax_idx;
-  }
+  if (!split && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
+  const int nwaves = ntile;
   const bool nt = zblocks == 1;  // weights read once per launch
   const int slices = split ? chains : 1;
   // waves per block: 4 share one LDS copy of the activations; 2 when that would leave CUs without a block
@@ -451,15 +446,14 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
     const size_t lds = (size_t)nrb * 16 * 1024;
     const u32x4* xp = reinterpret_cast<const u32x4*>(x);
     const u32x4* wp = reinterpret_cast<const u32x4*>(w);
-#define DOTB(B_, S_, E_)                                                                                                        \
-  do {                                                                                                                          \
-    if (nt) hipLaunchKernelGGL((k_dotb<B_, S_, E_, true>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS, zblocks);     \
-    else hipLaunchKernelGGL((k_dotb<B_, S_, E_, false>), grid, block, lds, st, xp, wp, K, N, R, out, av, ai, nwaves, TS, zblocks);       \
+#define DOTB(B_, S_)                                                                                              \
+  do {                                                                                                            \
+    if (nt) hipLaunchKernelGGL((k_dotb<B_, S_, true>), grid, block, lds, st, xp, wp, K, N, R, out, nwaves, zblocks);   \
+    else hipLaunchKernelGGL((k_dotb<B_, S_, false>), grid, block, lds, st, xp, wp, K, N, R, out, nwaves, zblocks);     \
   } while (0)
-#define DOTB_B(S_, E_) do { if (nrb == 4) DOTB(4, S_, E_); else if (nrb == 2) DOTB(2, S_, E_); else DOTB(1, S_, E_); } while (0)
-    if (epi_argmax) DOTB_B(false, 1);
-    else if (split) DOTB_B(true, 0);
-    else DOTB_B(false, 0);
+#define DOTB_B(S_) do { if (nrb == 4) DOTB(4, S_); else if (nrb == 2) DOTB(2, S_); else DOTB(1, S_); } while (0)
+    if (split) DOTB_B(true);
+    else DOTB_B(false);
 #undef DOTB_B
 #undef DOTB
   }
@@ -541,14 +535,6 @@ static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, co
   else hipLaunchKernelGGL((k_rownorm<2>), dim3(R), dim3(256), lds, st, a);
   LAUNCHCHK();
   return IXT_OK;
-}
-
-// h_out = bf16(h_in + bf16(sum slices)); xn = rmsnorm(h_out) * scale  (two launches: wide slice sum, then one block per row)
-static int launch_sumres_norm(ixt_ctx* c, int R, const DotResult* part, const bf16_t* h_in, bf16_t* h_out, const bf16_t* scale, bf16_t* xn_out,
-                              hipStream_t st) {
-  hipLaunchKernelGGL(k_sumres, dim3((c->E + 255) / 256, R), dim3(128), 0, st, c->part, part->slices, part->slice_stride, h_in, h_out, c->E);
-  LAUNCHCHK();
-  return launch_rownorm(c, 2, R, nullptr, nullptr, h_out, nullptr, scale, xn_out, st);
 }
 
 template <int HD, int GQ>

@@ -60,54 +60,35 @@ __host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
 }
 __host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xidx(n, k, K); }
 
-// EPI = 1 (only with !SPLIT): greedy-sampling epilogue (decoders.py:570 + inference_utils.py:74-75): the totals are rounded to
-// bf16, optionally stored as f32 logits, and each wave emits its (max, first index) pair per row for k_argmax_final.
 //   grid = (ceil(waves/WPB) * ceil(rowblocks/NRB), SPLIT ? chains : 1), block = WPB waves (blockDim.x / 64), LDS = NRB x 16 KiB.
-//   A block = WPB adjacent 16-column tiles x one chain at a time x NRB 16-row blocks.  Per chain: every wave first issues the
-//   loads of its 16 weight fragments (16 x 1 KiB, all in flight together, HBM), then the block copies the chain's activation
-//   slab (NRB x 16 fragments, L2) into LDS once for all its waves, and each wave runs 16 x NRB MFMAs reading the activation
+//   A block = WPB adjacent 16-column tiles x one chain at a time x NRB 16-row blocks.  Per chain: every wave issues the loads
+//   of its 16 weight fragments (16 x 1 KiB, all in flight together, HBM), the block copies the chain's activation slab
+//   (NRB x 16 fragments, L2) into LDS once for all its waves, and each wave runs 16 x NRB MFMAs reading the activation
 //   fragments from LDS.  Without the LDS copy every wave pulls the whole slab through L2 itself: 4x the weight bytes at 64 rows.
-//   TS (EPI only): a wave walks TS consecutive tiles keeping a running (max, first index).
-template <int NRB, bool SPLIT, int EPI, bool NT>
+//   SPLIT (one chain per block, 256 threads): the slab loads are issued BEFORE the weight loads -- loads return in order, so
+//   the L2-resident slab lands and is written to LDS while the weight fragments are still on their way from HBM.
+template <int NRB, bool SPLIT, bool NT>
 __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
-                                                 float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
-                                                 int nwaves, int TS, int zblocks) {
+                                                 float* __restrict__ out, int nwaves, int zblocks) {
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, nthr = blockDim.x, wpb = nthr >> 6;
   const int wave = tid >> 6, lane = tid & 63;
   // Blocks that stream the same weights (the row-block groups of one tile group) must share an L2: consecutive block ids are
   // dealt round-robin over the 8 XCDs, so the row-block group is taken from (blockIdx.x / 8) and ids b, b + 8, .. are partners.
   const int bx = blockIdx.x;
-  const int wid = ((bx / (8 * zblocks)) * 8 + (bx & 7)) * wpb + wave;
-  const int nsteps = K >> 5, ntile = N >> 4;
+  const int tile = ((bx / (8 * zblocks)) * 8 + (bx & 7)) * wpb + wave;
+  const int nsteps = K >> 5;
   const int nchains = (nsteps + 15) >> 4;
   const int nrbk = (R + 15) >> 4;
   const int rb0 = ((bx >> 3) % zblocks) * NRB;
   const int c_begin = SPLIT ? (int)blockIdx.y : 0, c_end = SPLIT ? (int)blockIdx.y + 1 : nchains;
   const int r_in = lane & 15, cq = lane >> 4;
-  float best[NRB];
-  int bidx[NRB];
+  const bool tile_ok = tile < nwaves;
+  const u32x4* wbase = wt + (size_t)(tile_ok ? tile : 0) * nsteps * 64 + lane;
+  f32x4 tot[NRB];
 #pragma unroll
-  for (int b = 0; b < NRB; ++b) { best[b] = -INFINITY; bidx[b] = 0x7fffffff; }
-  // activation slab of chain c -> LDS (row block b at xs[b*1024 ...]: cs*64 consecutive 16-byte elements).  The slab loads
-  // are issued BEFORE the weight loads of the same chain: loads return in order, so the (L2-resident) slab lands and is
-  // written to LDS while the weight fragments are still on their way from HBM.
-#define IXT_XSTAGE(C_)                                                                                             \
-  do {                                                                                                             \
-    const int s0_ = (C_) * 16, cs_ = min(16, nsteps - s0_);                                                        \
-    for (int e = tid; e < NRB * cs_ * 64; e += nthr) {                                                             \
-      const int b = e / (cs_ * 64), rem = e - b * (cs_ * 64);                                                      \
-      xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0_) * 64 + rem] : u32x4(0);       \
-    }                                                                                                              \
-  } while (0)
-  for (int ti = 0; ti < TS; ++ti) {
-    const int tile = wid * TS + ti;
-    const bool tile_ok = wid < nwaves && tile < ntile;
-    const u32x4* wbase = wt + (size_t)(tile_ok ? tile : 0) * nsteps * 64 + lane;
-    f32x4 tot[NRB];
-#pragma unroll
-    for (int b = 0; b < NRB; ++b) tot[b] = f32x4(0.0f);
-    u32x4 wv[16];
+  for (int b = 0; b < NRB; ++b) tot[b] = f32x4(0.0f);
+  u32x4 wv[16];
 #define IXT_WLOAD(S_, STEP_)                                                                     \
   do {                                                                                           \
     if (tile_ok && (STEP_) < nsteps) {                                                           \
@@ -115,95 +96,67 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
       else wv[S_] = wbase[(size_t)(STEP_) * 64];                                                 \
     }                                                                                            \
   } while (0)
-    if (ti > 0) __syncthreads();                        // every wave is done reading the previous slab
-    u32x4 xq[SPLIT ? NRB * 4 : 1];                      // split-K: one chain per block, slab fetched straight into registers first
-    if constexpr (SPLIT) {
-      const int cs_ = min(16, nsteps - c_begin * 16);
+  u32x4 xq[SPLIT ? NRB * 4 : 1];                        // split-K: the one slab of this block, fetched into registers first
+  if constexpr (SPLIT) {
+    const int cs_ = min(16, nsteps - c_begin * 16);
+#pragma unroll
+    for (int j = 0; j < NRB * 4; ++j) {
+      const int e = tid + j * nthr, b = e / (cs_ * 64), rem = e - b * (cs_ * 64);
+      xq[j] = (e < NRB * cs_ * 64 && rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + c_begin * 16) * 64 + rem] : u32x4(0);
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) IXT_WLOAD(s, c_begin * 16 + s);
+  for (int c = c_begin; c < c_end; ++c) {
+    const int s0 = c * 16;
+    const int cs = min(16, nsteps - s0);              // steps of this chain
+    // activation slab of this chain -> LDS (row block b at xs[b*1024 ...]: cs*64 consecutive 16-byte elements)
+    if constexpr (SPLIT) {   // (split-K launches use 256-thread blocks: NRB * 4 slab elements per thread)
 #pragma unroll
       for (int j = 0; j < NRB * 4; ++j) {
-        const int e = tid + j * nthr, b = e / (cs_ * 64), rem = e - b * (cs_ * 64);
-        xq[j] = (e < NRB * cs_ * 64 && rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + c_begin * 16) * 64 + rem] : u32x4(0);
+        const int e = tid + j * nthr, b = e / (cs * 64), rem = e - b * (cs * 64);
+        if (e < NRB * cs * 64) xs[b * 1024 + rem] = xq[j];
+      }
+    } else {
+      if (c > c_begin) __syncthreads();               // every wave is done reading the previous slab
+      for (int e = tid; e < NRB * cs * 64; e += nthr) {
+        const int b = e / (cs * 64), rem = e - b * (cs * 64);
+        xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0) * 64 + rem] : u32x4(0);
       }
     }
+    __syncthreads();
+    f32x4 acc[NRB];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) IXT_WLOAD(s, c_begin * 16 + s);
-    for (int c = c_begin; c < c_end; ++c) {
-      const int s0 = c * 16;
-      const int cs = min(16, nsteps - s0);              // steps of this chain
-      if constexpr (SPLIT) {   // (split-K launches use 256-thread blocks: NRB * 4 slab elements per thread)
+    for (int b = 0; b < NRB; ++b) acc[b] = f32x4(0.0f);
 #pragma unroll
-        for (int j = 0; j < NRB * 4; ++j) {
-          const int e = tid + j * nthr, b = e / (cs * 64), rem = e - b * (cs * 64);
-          if (e < NRB * cs * 64) xs[b * 1024 + rem] = xq[j];
-        }
-      } else {
-        if (c > c_begin) __syncthreads();
-        IXT_XSTAGE(c);
-      }
-      __syncthreads();
-      f32x4 acc[NRB];
+    for (int s = 0; s < 16; ++s) {
+      if (s < cs) {
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, wv[s]);
 #pragma unroll
-      for (int b = 0; b < NRB; ++b) acc[b] = f32x4(0.0f);
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        if (s < cs) {
-          const bf16x8 wf = __builtin_bit_cast(bf16x8, wv[s]);
-#pragma unroll
-          for (int b = 0; b < NRB; ++b)
-            acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xs[b * 1024 + s * 64 + lane]), acc[b], 0, 0, 0);
-          if (!SPLIT && c + 1 < c_end) IXT_WLOAD(s, s0 + 16 + s);
-        }
-      }
-      if (SPLIT) {
-#pragma unroll
-        for (int b = 0; b < NRB; ++b) {
-          const int row = (rb0 + b) * 16 + r_in;
-          if (tile_ok && row < R)
-            *reinterpret_cast<float4*>(out + ((size_t)c * R + row) * N + tile * 16 + cq * 4) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
-        }
-      } else {
-#pragma unroll
-        for (int b = 0; b < NRB; ++b) tot[b] = tot[b] + acc[b];
+        for (int b = 0; b < NRB; ++b)
+          acc[b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, __builtin_bit_cast(bf16x8, xs[b * 1024 + s * 64 + lane]), acc[b], 0, 0, 0);
+        if (!SPLIT && c + 1 < c_end) IXT_WLOAD(s, s0 + 16 + s);   // refill with the next chain's fragment
       }
     }
-#undef IXT_WLOAD
-#undef IXT_XSTAGE
-    if (!SPLIT && tile_ok) {
+    if (SPLIT) {
 #pragma unroll
       for (int b = 0; b < NRB; ++b) {
         const int row = (rb0 + b) * 16 + r_in;
-        if (EPI == 0) {
-          if (row < R)
-            *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[b][0], tot[b][1], tot[b][2], tot[b][3]);
-        } else {
-          // running (max, first index) over this wave's tiles (ascending columns: a later equal value never replaces)
-          float v[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = rbf(tot[b][j]);
-          if (out != nullptr && row < R) *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (v[j] > best[b]) { best[b] = v[j]; bidx[b] = tile * 16 + cq * 4 + j; }
-        }
+        if (tile_ok && row < R)
+          *reinterpret_cast<float4*>(out + ((size_t)c * R + row) * N + tile * 16 + cq * 4) = make_float4(acc[b][0], acc[b][1], acc[b][2], acc[b][3]);
       }
+    } else {
+#pragma unroll
+      for (int b = 0; b < NRB; ++b) tot[b] = tot[b] + acc[b];
     }
   }
-  if (EPI == 1 && wid < nwaves) {
+#undef IXT_WLOAD
+  if (!SPLIT && tile_ok) {
 #pragma unroll
     for (int b = 0; b < NRB; ++b) {
-      float bv = best[b];
-      int bi = bidx[b];
-#pragma unroll
-      for (int off = 16; off < 64; off <<= 1) {   // the 4 lanes of a row are lanes r, r+16, r+32, r+48
-        const float ov = __shfl_xor(bv, off, 64);
-        const int oi = __shfl_xor(bi, off, 64);
-        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-      }
       const int row = (rb0 + b) * 16 + r_in;
-      if (cq == 0 && row < R) {
-        amax_val[(size_t)row * nwaves + wid] = bv;
-        amax_idx[(size_t)row * nwaves + wid] = bi;
-      }
+      if (row < R)
+        *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[b][0], tot[b][1], tot[b][2], tot[b][3]);
     }
   }
 }
@@ -380,35 +333,6 @@ __global__ __launch_bounds__(128) void k_sumres(const float* part, int slices, s
   const uint32_t hv = *reinterpret_cast<const uint32_t*>(h_in + (size_t)r * E + c);
   const bf16_t a = f2bf(bflo(hv) + rbf(o.x)), b = f2bf(bfhi(hv) + rbf(o.y));
   *reinterpret_cast<uint32_t*>(h_out + (size_t)r * E + c) = pack2(a, b);
-}
-
-// h_out = bf16(h_in + bf16(sum of slices)) AND the per-chunk sums of squares of h_out (chunk = 8 consecutive elements,
-// one fma chain -- the first level of the canonical RMSNorm reduction; the consumer finishes it).
-// grid = (ceil(E/128), R), block 64: thread t owns 2 columns; chunk = 4 consecutive threads.
-__global__ __launch_bounds__(64) void k_sumres_chunk(const float* part, int slices, size_t slice_stride, const bf16_t* h_in, bf16_t* h_out,
-                                                     float* chunk, int E) {
-  const int r = blockIdx.y, t = threadIdx.x;
-  const int c = blockIdx.x * 128 + t * 2;
-  float h0 = 0.0f, h1 = 0.0f;
-  if (c < E) {
-    const float2 o = sum_slices2<16>(part + (size_t)r * E + c, slice_stride, slices);
-    const uint32_t hv = *reinterpret_cast<const uint32_t*>(h_in + (size_t)r * E + c);
-    h0 = rbf(bflo(hv) + rbf(o.x));
-    h1 = rbf(bfhi(hv) + rbf(o.y));
-    *reinterpret_cast<uint32_t*>(h_out + (size_t)r * E + c) = pack2(f2bf(h0), f2bf(h1));
-  }
-  // chain over the chunk's 8 elements in order: thread q of the chunk continues the chain of thread q-1
-  float a = 0.0f;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const float prev = __shfl_up(a, 1, 64);
-    if ((t & 3) == q) {
-      if (q > 0) a = prev;
-      a = __builtin_fmaf(h0, h0, a);
-      a = __builtin_fmaf(h1, h1, a);
-    }
-  }
-  if ((t & 3) == 3 && c < E) chunk[(size_t)r * (E / 8) + c / 8] = a;
 }
 
 // =====================================================================================================
@@ -1153,35 +1077,6 @@ __global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, co
   const float sn = bf2f(rope_sin[(size_t)pos[r] * half + i]), cs = bf2f(rope_cos[(size_t)pos[r] * half + i]);
   p[i] = f2bf(rbf(x1 * cs) - rbf(x2 * sn));
   p[half + i] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
-}
-
-// =====================================================================================================
-// Greedy sampling (inference_utils.py:74-75): logits f32 [R][V] (unrounded canonical totals) are rounded to
-// bf16 (logits_dot_in_fp32 = False, decoders.py:570) in place, argmax = FIRST index of the maximum.
-// grid = R, block 1024.
-// =====================================================================================================
-__global__ __launch_bounds__(1024) void k_round_argmax(float* logits, int V, int32_t* out_idx, float* logits_copy) {
-  __shared__ float bv[1024];
-  __shared__ int bi[1024];
-  const int r = blockIdx.x, tid = threadIdx.x;
-  float* row = logits + (size_t)r * V;
-  float best = -INFINITY;
-  int idx = 0x7fffffff;
-  for (int n = tid; n < V; n += 1024) {
-    const float v = rbf(row[n]);
-    if (logits_copy) logits_copy[(size_t)r * V + n] = v;
-    if (v > best || (v == best && n < idx)) { best = v; idx = n; }
-  }
-  bv[tid] = best; bi[tid] = idx;
-  __syncthreads();
-  for (int s = 512; s > 0; s >>= 1) {
-    if (tid < s) {
-      const float v = bv[tid + s]; const int i2 = bi[tid + s];
-      if (v > bv[tid] || (v == bv[tid] && i2 < bi[tid])) { bv[tid] = v; bi[tid] = i2; }
-    }
-    __syncthreads();
-  }
-  if (tid == 0) out_idx[r] = bi[0] == 0x7fffffff ? 0 : bi[0];
 }
 
 // =====================================================================================================
