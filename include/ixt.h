@@ -152,6 +152,12 @@ int ixt_timing_reset(ixt_ctx* ctx);
 int ixt_timing_get(ixt_ctx* ctx, const char* family, double* avg_us, int64_t* launches, double* bytes_per_launch);
 
 
+/* Greedy sampling restricted to the union of `nranges` (0..4) half-open column ranges lo_hi[2i], lo_hi[2i+1] (host array);
+ * nranges == 0 lifts the restriction.  SURVEY.md section 8(f) item 1: the expanded vocabulary keeps the audio codes in rows
+ * 6..104 and 256001..264093 (audio_token_mapping_adjusted.json, generator vocab_expansion/extend_tokenizer.py:29-46); with
+ * these two ranges every generated id maps back to an audio code.  Logits are returned unmasked. */
+int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
+
 /* Launch-shape knobs of this build (no counterpart in the reference; results never depend on them, tests use them to drive
  * every kernel variant on small configurations):
  *   "attn_fused_min_blocks"  decode attention runs as one launch per layer once rows x kv_heads reaches this (default 128) */

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ixt_timing_reset": (ctypes.c_int, [vp]),
     "ixt_timing_get": (ctypes.c_int, [vp, ctypes.c_char_p, c_f64p, c_i64p, c_f64p]),
     "ixt_set_option": (ctypes.c_int, [vp, ctypes.c_char_p, ctypes.c_int]),
+    "ixt_set_sampling_ranges": (ctypes.c_int, [vp, vp, ctypes.c_int]),
 }
 
 _lib = None

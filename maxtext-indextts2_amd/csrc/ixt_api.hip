@@ -73,6 +73,7 @@ struct ixt_ctx {
   // timing
   bool timing = false;
   int attn_fused_min_blocks = 128;
+  ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
   // graphs keyed by the pointer tuple of ixt_generate
@@ -480,8 +481,8 @@ static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out
   const u32x4* wp = reinterpret_cast<const u32x4*>(c->logits_w);
 #define UNEMB(B_)                                                                                                                          \
   do {                                                                                                                                     \
-    if (zblocks == 1) hipLaunchKernelGGL((k_unembed<B_, true>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks); \
-    else hipLaunchKernelGGL((k_unembed<B_, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks);           \
+    if (zblocks == 1) hipLaunchKernelGGL((k_unembed<B_, true>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols); \
+    else hipLaunchKernelGGL((k_unembed<B_, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols);           \
   } while (0)
   if (nrb == 4) UNEMB(4); else if (nrb == 2) UNEMB(2); else UNEMB(1);
 #undef UNEMB
@@ -865,7 +866,23 @@ extern "C" int ixt_rope_tables(ixt_ctx* c, uint16_t* sin_out, uint16_t* cos_out)
   return IXT_OK;
 }
 
-// --------------------------------------------------------------------------------------- options, timing
+// --------------------------------------------------------------------------------------- sampling columns, options, timing
+extern "C" int ixt_set_sampling_ranges(ixt_ctx* c, const int32_t* lo_hi, int nranges) {
+  if (!c || nranges < 0 || nranges > 4 || (nranges > 0 && !lo_hi)) return set_err(IXT_ERR_INVALID, "0..4 ranges");
+  ColRanges cr{};
+  for (int i = 0; i < nranges; ++i) {
+    const int lo = lo_hi[2 * i], hi = lo_hi[2 * i + 1];
+    if (lo < 0 || hi > c->V || lo >= hi) return set_err(IXT_ERR_RANGE, "sampling range [%d, %d) outside [0, %d)", lo, hi, c->V);
+    cr.lo[i] = lo; cr.hi[i] = hi;
+  }
+  cr.n = nranges;
+  HIPCHK(hipDeviceSynchronize());
+  for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launches carry the old ranges as kernel arguments
+  c->graphs.clear();
+  c->sample_cols = cr;
+  return IXT_OK;
+}
+
 extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
   if (!c || !name) return set_err(IXT_ERR_INVALID, "null argument");
   if (strcmp(name, "attn_fused_min_blocks") == 0) {

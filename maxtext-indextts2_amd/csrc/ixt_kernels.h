@@ -172,10 +172,22 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
 //   stored as f32) are written only when `out` is given.   grid = ceil(V/256) * ceil(rowblocks/NRB), block 256,
 //   LDS = NRB x 16 KiB.
 // =====================================================================================================
+// Columns the greedy sampler may pick: the union of up to 4 half-open ranges (n == 0: every column).  The expanded vocabulary
+// keeps the audio codes in two runs of rows (6..104 and 256001..264093, audio_token_mapping_adjusted.json); restricting the
+// argmax to them makes every generated id an audio id.  The logits themselves are not touched.
+struct ColRanges { int n; int lo[4]; int hi[4]; };
+__device__ __forceinline__ bool col_allowed(const ColRanges& cr, int col) {
+  if (cr.n == 0) return true;
+  bool ok = false;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ok = ok || (i < cr.n && col >= cr.lo[i] && col < cr.hi[i]);
+  return ok;
+}
+
 template <int NRB, bool NT>
 __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                     float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
-                                                    int nwaves, int zblocks) {
+                                                    int nwaves, int zblocks, ColRanges cr) {
   constexpr int TS = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -268,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
         if (out != nullptr && row < R) *reinterpret_cast<float4*>(out + (size_t)row * N + (tile0 + t) * 16 + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (v[j] > bv) { bv = v[j]; bi = (tile0 + t) * 16 + cq * 4 + j; }   // ascending columns: a later equal value never replaces
+          if (v[j] > bv && col_allowed(cr, (tile0 + t) * 16 + cq * 4 + j)) { bv = v[j]; bi = (tile0 + t) * 16 + cq * 4 + j; }   // ascending columns: a later equal value never replaces
       }
     }
 #pragma unroll
@@ -861,17 +873,21 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
   const int QN = g.nq * HD, KN = g.nkv * HD;
 
-  // first key tile of this wave: loads issued before the prologue
-  u32x4 kv[HD / 8];
-#define IXT_KLOAD(DST_, PS_)                                                                                      \
+  // Score work of this wave as a flat list of half tiles: tile i = keys of pages (wave + 4 i) ppw .., half h = d-chunks
+  // h HD/16 .. (h + 1) HD/16 - 1 of the lane's key.  Two register buffers of HD/16 x 16 bytes; the first half tile is in flight
+  // before the prologue, and every later one before the fma chains of its predecessor.
+  constexpr int KH = HD / 16;             // d-chunks per half tile
+  u32x4 ka[KH], kb[KH];
+#define IXT_KLOAD(DST_, F_)                                                                                       \
   do {                                                                                                            \
-    const int pidx_ = (PS_) * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                    \
-    if ((PS_) * ppw < pages && j_ < kv_len && j_ != pos) {                                                        \
-      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, 0, lane % g.P);                               \
-      _Pragma("unroll") for (int dc = 0; dc < HD / 8; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
+    const int ps_ = wave + 4 * ((F_) >> 1), h_ = (F_) & 1;                                                        \
+    const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
+    if (ps_ * ppw < pages && j_ < kv_len && j_ != pos) {                                                          \
+      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, h_ * KH, lane % g.P);                         \
+      _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
     }                                                                                                             \
   } while (0)
-  IXT_KLOAD(kv, wave);
+  IXT_KLOAD(ka, 0);
 
   // prologue: q heads, new k, new v of this kv head from the QKV slices (+ RoPE), K/V page write
   for (int idx = tid; idx < (GQ + 2) * half; idx += 256) {
@@ -905,45 +921,47 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   }
   __syncthreads();
 
-  // scores: lane = key; the next tile's loads are issued before the current tile's fma chains
-  for (int ps = wave; ps * ppw < pages; ps += 4) {
-    u32x4 kx[HD / 8];
-    IXT_KLOAD(kx, ps + 4);
-    const int pidx = ps * ppw + lane / g.P, j = pidx * g.P + lane % g.P;
-    if (j < kv_len) {
-      float acc[GQ];
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) acc[q] = 0.0f;
-      if (j == pos) {
-#pragma unroll 8
-        for (int d = 0; d < HD; ++d) {
-#pragma unroll
-          for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);
-        }
-      } else {
-#pragma unroll
-        for (int dc = 0; dc < HD / 8; ++dc) {
-          const float kf[8] = {bflo(kv[dc].x), bfhi(kv[dc].x), bflo(kv[dc].y), bfhi(kv[dc].y),
-                               bflo(kv[dc].z), bfhi(kv[dc].z), bflo(kv[dc].w), bfhi(kv[dc].w)};
-#pragma unroll
-          for (int q = 0; q < GQ; ++q) {
-            const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8);
-            const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + dc * 8 + 4);
-            float sacc = acc[q];
-            sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);
-            sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);
-            sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);
-            sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);
-            acc[q] = sacc;
-          }
-        }
-      }
-#pragma unroll
-      for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * g.Tmax + j] = acc[q];
+  // scores: lane = key; one fma chain over d per (key, q head), continued across the two halves
+#define IXT_KHALF(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = wave + 4 * ((F_) >> 1), h_ = (F_) & 1;                                                        \
+    const int j_ = (ps_ * ppw + lane / g.P) * g.P + lane % g.P;                                                   \
+    if (h_ == 0) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = 0.0f; }                                \
+    if (j_ < kv_len) {                                                                                            \
+      if (j_ == pos) {   /* the key this block has just written: from LDS */                                      \
+        for (int d = h_ * (HD / 2); d < (h_ + 1) * (HD / 2); ++d) {                                               \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);  \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) {                                                       \
+          const float kf[8] = {bflo(BUF_[dc].x), bfhi(BUF_[dc].x), bflo(BUF_[dc].y), bfhi(BUF_[dc].y),            \
+                               bflo(BUF_[dc].z), bfhi(BUF_[dc].z), bflo(BUF_[dc].w), bfhi(BUF_[dc].w)};           \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                        \
+            const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8);                 \
+            const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8 + 4);             \
+            float sacc = acc[q];                                                                                  \
+            sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);                   \
+            sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);                   \
+            sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);                   \
+            sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);                   \
+            acc[q] = sacc;                                                                                        \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
+      if (h_ == 1) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * g.Tmax + j_] = acc[q]; }     \
+    }                                                                                                             \
+  } while (0)
+  {
+    const int ntile = (pages > wave * ppw) ? (pages - wave * ppw + 4 * ppw - 1) / (4 * ppw) : 0;
+    float acc[GQ];
+    for (int f = 0; f < 2 * ntile; f += 2) {
+      IXT_KLOAD(kb, f + 1);
+      IXT_KHALF(ka, f);
+      IXT_KLOAD(ka, f + 2);
+      IXT_KHALF(kb, f + 1);
     }
-#pragma unroll
-    for (int dc = 0; dc < HD / 8; ++dc) kv[dc] = kx[dc];
   }
+#undef IXT_KHALF
 #undef IXT_KLOAD
   __syncthreads();
 

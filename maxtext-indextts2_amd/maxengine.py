@@ -123,6 +123,22 @@ class MaxEngine(engine_api.Engine):
     self._params_loaded = True
     return {"params": "resident in HBM (libixt)", "engine": id(self)}
 
+  # ------------------------------------------------------------------ sampling columns
+  def set_sampling_ranges(self, ranges) -> None:
+    """Restrict greedy sampling to the union of up to 4 half-open column ranges [(lo, hi), ...]; [] or None lifts it.
+    With `AudioTokenMapping.audio_row_ranges()` every generated id is the row of an audio code.  Logits stay unmasked."""
+    ranges = list(ranges or [])
+    arr = (ctypes.c_int32 * max(1, 2 * len(ranges)))(*[int(v) for r in ranges for v in r])
+    _lib.check(self.lib.ixt_set_sampling_ranges(self._ctx, arr, len(ranges)))
+
+  def set_audio_only_sampling(self, mapping=None) -> None:
+    """Sample audio codes only: ranges from `mapping` (an AudioTokenMapping) or from config.audio_token_mapping_path (base.yml:496)."""
+    if mapping is None:
+      from .vocab_expansion import AudioTokenMapping  # pylint: disable=import-outside-toplevel
+      path = self.config.audio_token_mapping_path
+      mapping = AudioTokenMapping.from_npz(path) if path.endswith(".npz") else AudioTokenMapping.from_json(path)
+    self.set_sampling_ranges(mapping.audio_row_ranges())
+
   # ------------------------------------------------------------------ prefill
   def prefill(self, *, params: Params, existing_prefix: Optional[ExistingPrefix] = None, padded_tokens: Any, images: Any = None,
               true_length: int, sampler: Any = None, rng: Any = None, request_id: Any = None, slot: Optional[int] = None,

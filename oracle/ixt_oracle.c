@@ -447,6 +447,22 @@ void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int3
   }
 }
 
+/* ---------------------------------------------------------------- sampling columns */
+/* greedy sampling restricted to a union of up to 4 half-open column ranges (the audio rows of
+ * the expanded vocabulary); n == 0: every column. */
+static int orc_nranges = 0;
+static int32_t orc_lo[4], orc_hi[4];
+void orc_set_sampling_ranges(const int32_t* lo_hi, int n) {
+  orc_nranges = n < 0 ? 0 : (n > 4 ? 4 : n);
+  for (int i = 0; i < orc_nranges; ++i) { orc_lo[i] = lo_hi[2 * i]; orc_hi[i] = lo_hi[2 * i + 1]; }
+}
+static inline int orc_col_allowed(int n) {
+  if (orc_nranges == 0) return 1;
+  for (int i = 0; i < orc_nranges; ++i)
+    if (n >= orc_lo[i] && n < orc_hi[i]) return 1;
+  return 0;
+}
+
 /* ---------------------------------------------------------------- forward */
 /* R rows processed as one ragged batch (a prefill chunk of one slot, or one decode
  * token for each of several slots).  Per layer ALL rows' K/V are written to their
@@ -537,14 +553,17 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
     orc_dot_rows(y, E, n_logits, m->logits_w, E, m->vocab, lg, m->vocab);
     for (int i = 0; i < n_logits; ++i) {
       float* row = lg + (size_t)i * m->vocab;
-      int best = 0;
-      float bv = rbf(row[0]);
-      row[0] = bv;
-      for (int n = 1; n < m->vocab; ++n) {
+      /* first index of the maximum over the allowed columns (all columns unless orc_set_sampling_ranges restricted them;
+       * no allowed column at all -> 0) */
+      int best = -1;
+      float bv = -INFINITY;
+      for (int n = 0; n < m->vocab; ++n) {
         float vv = rbf(row[n]);
         row[n] = vv;
-        if (vv > bv) { bv = vv; best = n; }
+        if (!orc_col_allowed(n)) continue;
+        if (best < 0 || vv > bv) { bv = vv; best = n; }
       }
+      if (best < 0) best = 0;
       if (argmax_out) argmax_out[i] = best;
       if (logits_out) memcpy(logits_out + (size_t)i * m->vocab, row, sizeof(float) * m->vocab);
     }

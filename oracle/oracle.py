@@ -69,6 +69,7 @@ def lib():
     _lib.orc_dot_rows.argtypes = [_u16p, ctypes.c_int, ctypes.c_int, _u16p, ctypes.c_int, ctypes.c_int, _f32p, ctypes.c_int]
     _lib.orc_dot_rows_scalar.argtypes = _lib.orc_dot_rows.argtypes
     _lib.orc_mfma_cases.argtypes = [_u16p, _u16p, _f32p, _f32p, ctypes.c_int64]
+    _lib.orc_set_sampling_ranges.argtypes = [_i32p, ctypes.c_int]
     _lib.orc_attend_row.argtypes = [ctypes.POINTER(_CModel), ctypes.c_int, _u16p, _i32p, ctypes.c_int, _u16p, _f32p]
     _lib.orc_f32_to_bf16.argtypes = [_f32p, _u16p, ctypes.c_int64]
     _lib.orc_exp_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
@@ -397,6 +398,13 @@ class OracleEngine:
     self.pm = PageManager(c.pagedattn_num_pages, c.pagedattn_tokens_per_page, c.max_target_length, c.max_slots,
                           c.pagedattn_max_pages_per_group)
     self.page_state = self.pm.get_initial_page_state()
+
+  @staticmethod
+  def set_sampling_ranges(ranges):
+    """Greedy sampling restricted to half-open column ranges [(lo, hi), ...] (library-wide state of the oracle; [] lifts it)."""
+    ranges = list(ranges or [])
+    arr = np.array([v for r in ranges for v in r] or [0], np.int32)
+    lib().orc_set_sampling_ranges(_p(arr, _i32p), len(ranges))
 
   def prefill(self, padded_tokens, true_length, slot=0, existing_prefix_tokens=None, want_logits=False):
     start = 0 if existing_prefix_tokens is None else len(existing_prefix_tokens)

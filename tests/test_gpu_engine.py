@@ -17,13 +17,24 @@ def assert_pages_equal(eng, orc):
     assert np.array_equal(st[f], getattr(orc.page_state, f)), f
 
 
-def run_pair(cfg, weights, prompts, steps, use_graph=True, check_logits=True, chunks=None, options=None):
+def run_pair(cfg, weights, prompts, steps, use_graph=True, check_logits=True, chunks=None, options=None, sampling_ranges=None):
   """prompts: list of (padded_tokens, true_length) one per slot (len <= batch).  Returns HIP token matrix."""
   import torch
   eng, params = H.make_engine(cfg, weights)
   for name, value in (options or {}).items():
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, name.encode(), int(value)))
   orc = H.make_oracle(cfg, weights)
+  if sampling_ranges is not None:
+    eng.set_sampling_ranges(sampling_ranges)
+    orc.set_sampling_ranges(sampling_ranges)
+  try:
+    return _run_pair(cfg, eng, params, orc, prompts, steps, check_logits, chunks)
+  finally:
+    orc.set_sampling_ranges([])
+
+
+def _run_pair(cfg, eng, params, orc, prompts, steps, check_logits, chunks):
+  import torch
   B = int(cfg.per_device_batch_size)
   prefixes, oprefixes = [], []
   for slot, (toks, tl) in enumerate(prompts):
@@ -114,6 +125,19 @@ def test_tiny_one_launch_decode_attention(B, nprompts):
     toks, _ = H.synth.synth_prompt(cfg.vocab_size, cfg.max_prefill_predict_length, 300 + s)
     prompts.append((toks, [32, 1, 9, 17, 8, 31, 16, 24][s % 8]))
   run_pair(cfg, w, prompts, steps=40, options={"attn_fused_min_blocks": 1})
+
+
+def test_audio_only_sampling_ranges():
+  """greedy sampling restricted to column ranges (the audio rows of the expanded vocabulary): tokens equal the
+  oracle's restricted argmax, all lie inside the ranges, and the returned logits are the unmasked ones (checked by run_pair)."""
+  cfg = H.make_config(per_device_batch_size=3.0)
+  w = H.synth.synth_weights(cfg, 6)
+  prompts = [H.synth.synth_prompt(cfg.vocab_size, 32, 40 + s) for s in range(3)]
+  ranges = [(6, 105), (600, 900)]
+  got = run_pair(cfg, w, prompts, steps=24, sampling_ranges=ranges)
+  assert all(any(lo <= t < hi for lo, hi in ranges) for t in got.reshape(-1))
+  free = run_pair(cfg, w, prompts, steps=24)
+  assert not np.array_equal(free, got)
 
 
 def test_tiny_graph_equals_eager():
