@@ -73,6 +73,7 @@ struct ixt_ctx {
   // timing
   bool timing = false;
   int attn_fused_min_blocks = 128;
+  int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
@@ -429,8 +430,26 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   if (nrb_env == 1 || nrb_env == 2 || nrb_env == 4) nrb = nrb_env;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
   bool split = !force_full && chains > 1;
-  // (letting a block walk its chains itself at many rows -- one slice instead of `chains` -- was measured: 102 vs 54 us on the
-  //  2048 x 14336 kernel at 256 rows; the per-chain barriers and slab copies cost more than the slices)
+  // Many rows, few chains, many columns: the streaming kernel (the unembedding's structure, block = 128 columns x all chains x 64
+  // rows) adds the chain results on chip and writes ONE slice; at 256 rows the `chains` slices of a split-K launch are as large
+  // as the weights.  Kept behind an option (default off): with 2 resident blocks per CU and a barrier pair per chain it measured
+  // slightly SLOWER than split-K on the 2048 x 14336 and 2048 x 6144 kernels at 256 rows.  (Walking the chains inside k_dotb
+  // was worse still: 102 vs 54 us.)
+  const int stream_min_blocks = c->dot_stream_min_blocks;
+  if (!force_full && nrb == 4 && zblocks >= 2 && chains > 1 && chains <= 4 && (long)((ntile + 7) / 8) * zblocks >= stream_min_blocks &&
+      (size_t)R * N <= out_floats) {
+    const int nw = (ntile + 1) / 2;   // waves: one tile duo each
+    const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (double)R * N * 4.0);
+    dim3 grid((((nw + 3) / 4 + 7) / 8) * 8 * zblocks, 1, 1);
+    hipLaunchKernelGGL((k_unembed<4, false, 2, 0>), grid, dim3(256), (size_t)4 * 16 * 1024, st, reinterpret_cast<const u32x4*>(x),
+                       reinterpret_cast<const u32x4*>(w), K, N, R, out, (float*)nullptr, (int32_t*)nullptr, nw, zblocks, ColRanges{});
+    timing_end(c, st, ti);
+    LAUNCHCHK();
+    res->slices = 1;
+    res->slice_stride = (size_t)R * N;
+    res->ntiles = nw;
+    return IXT_OK;
+  }
   if (split && (size_t)chains * R * N > out_floats) split = false;
   if (!split && (size_t)R * N > out_floats) return set_err(IXT_ERR_INVALID, "dot: output workspace too small");
   const int nwaves = ntile;
@@ -481,8 +500,8 @@ static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out
   const u32x4* wp = reinterpret_cast<const u32x4*>(c->logits_w);
 #define UNEMB(B_)                                                                                                                          \
   do {                                                                                                                                     \
-    if (zblocks == 1) hipLaunchKernelGGL((k_unembed<B_, true>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols); \
-    else hipLaunchKernelGGL((k_unembed<B_, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols);           \
+    if (zblocks == 1) hipLaunchKernelGGL((k_unembed<B_, true, 4, 1>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols); \
+    else hipLaunchKernelGGL((k_unembed<B_, false, 4, 1>), grid, dim3(256), lds, st, xp, wp, K, N, R, logits_out, c->amax_val, c->amax_idx, nwaves, zblocks, c->sample_cols);           \
   } while (0)
   if (nrb == 4) UNEMB(4); else if (nrb == 2) UNEMB(2); else UNEMB(1);
 #undef UNEMB
@@ -891,6 +910,14 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launch sequences embed the old choice
     c->graphs.clear();
     c->attn_fused_min_blocks = value;
+    return IXT_OK;
+  }
+  if (strcmp(name, "dot_stream_min_blocks") == 0) {
+    if (value < 1) return set_err(IXT_ERR_RANGE, "dot_stream_min_blocks must be positive");
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+    c->graphs.clear();
+    c->dot_stream_min_blocks = value;
     return IXT_OK;
   }
   return set_err(IXT_ERR_INVALID, "unknown option %s", name);

@@ -184,11 +184,14 @@ __device__ __forceinline__ bool col_allowed(const ColRanges& cr, int col) {
   return ok;
 }
 
-template <int NRB, bool NT>
+// EPI = 1, TS = 4: the unembedding.  EPI = 0, TS = 2: the same streaming structure for a layer kernel at many rows (block = 128
+// columns x all chains): the chain results are added in the block, so ONE f32 slice leaves the chip instead of `chains`
+// (at 256 rows the slices of a split-K launch are as large as the weights).  Same bits as k_dotb: t = t + chain(c), c ascending.
+template <int NRB, bool NT, int TS, int EPI>
 __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                     float* __restrict__ out, float* __restrict__ amax_val, int32_t* __restrict__ amax_idx,
                                                     int nwaves, int zblocks, ColRanges cr) {
-  constexpr int TS = 4;
+  static_assert(TS == 2 || TS == 4, "one or two tile duos per wave");
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int bx = blockIdx.x;                                   // partners (same columns, other rows) are ids b, b + 8, ..: same XCD, same L2
@@ -259,13 +262,28 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
       xs[b * 1024 + rem] = (rb0 + b < nrbk) ? xt[((size_t)(rb0 + b) * nsteps + s0) * 64 + rem] : u32x4(0);
     }
     __syncthreads();
-    IXT_UDUO(0, c, 1);
-    IXT_UDUO(1, c + 1, 0);
+    if constexpr (TS == 4) {
+      IXT_UDUO(0, c, 1);
+      IXT_UDUO(1, c + 1, 0);
+    } else {
+      IXT_UDUO(0, c + 1, 0);
+    }
   }
 #undef IXT_ULOADQ
 #undef IXT_UMMAQ
 #undef IXT_UDUO
   if (wid >= nwaves) return;
+  if constexpr (EPI == 0) {
+#pragma unroll
+    for (int b = 0; b < NRB; ++b) {
+      const int row = (rb0 + b) * 16 + r_in;
+#pragma unroll
+      for (int t = 0; t < TS; ++t)
+        if (tile0 + t < ntile && row < R)
+          *reinterpret_cast<float4*>(out + (size_t)row * N + (tile0 + t) * 16 + cq * 4) = make_float4(tot[t][b][0], tot[t][b][1], tot[t][b][2], tot[t][b][3]);
+    }
+    return;
+  }
 #pragma unroll
   for (int b = 0; b < NRB; ++b) {
     const int row = (rb0 + b) * 16 + r_in;

@@ -52,6 +52,19 @@ def test_dot(ctx, R, K, N):
   _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
 
 
+@pytest.mark.parametrize("R,K,N", [(100, 2048, 256), (128, 1024, 272), (250, 1152, 128)])
+def test_dot_streaming_kernel(ctx, R, K, N):
+  """More than 64 rows, 2..4 chains: the streaming kernel (block = 128 columns x all chains, chain results added on chip, one
+  slice) forced onto small shapes; ragged last row block, a short last chain, a column count that is not a multiple of 128."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_stream_min_blocks", 1))
+  try:
+    rng = np.random.default_rng(R + K + N)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_stream_min_blocks", 1 << 30))
+
+
 @pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
 def test_dot_wide_exponents_and_zeros(ctx, spread, zero_frac):
   """The matrix-core arithmetic truncates small products against the largest one of each 8-k step: exercise wide exponent
