@@ -1086,6 +1086,237 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
 #undef IXT_VBATCH
 }
 
+// ---- the same one-launch decode attention with ONE WAVE per (row, kv head) pair and no block barrier at all: a block is just
+//      four independent waves.  Every phase is wave-local (max by shuffles, page sums by the page's owner lane, the in-order
+//      super-block sum kept in registers because one wave meets the super-blocks in order), so waves drift apart instead of
+//      marching through load-free phases in lockstep, and 16 pairs per CU are resident instead of 4.
+//      grid = ceil(R * nkv / 4), block 256; LDS per wave: (GQ + 2) * HD + GQ * Tmax + mpg floats.
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_decode_w(DecAttnArgs a, int npairs) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const AttnGeom& g = a.g;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int pair = blockIdx.x * 4 + wave;
+  if (pair >= npairs) return;
+  const int r = pair / g.nkv, kvh = pair % g.nkv;
+  const int n_out = g.nq * HD;
+  constexpr int LPP = HD / 8;             // lanes per page in the PV phase (d-chunks)
+  constexpr int PPW = 64 / LPP;           // pages per PV group (4 for hd 128, 8 for hd 64)
+  const int tq = lane / LPP, dc = lane % LPP;
+  if (!a.row_active[r]) {
+    if (tq == 0) {
+#pragma unroll
+      for (int q = 0; q < GQ; ++q) *reinterpret_cast<u32x4*>(a.out + xidx(r, (kvh * GQ + q) * HD + dc * 8, n_out)) = u32x4(0);
+    }
+    return;
+  }
+  const size_t per_wave = (size_t)(GQ + 2) * HD + (size_t)GQ * g.Tmax + g.mpg;
+  float* qs = sm + (size_t)wave * per_wave;     // [GQ][HD]
+  float* kn = qs + GQ * HD;                     // [HD] new key (bf16-rounded, as f32)
+  float* vn = kn + HD;                          // [HD] new value
+  float* ebuf = vn + HD;                        // [GQ][Tmax] scores -> exps -> P
+  float* psum = ebuf + (size_t)GQ * g.Tmax;     // [mpg]
+  const int pos = a.row_pos[r];
+  const int kv_len = pos + 1;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int ppw = 64 / g.P;                     // pages per score tile (lane = key)
+  constexpr int half = HD / 2;
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+  const int QN = g.nq * HD, KN = g.nkv * HD;
+
+  constexpr int KH = HD / 16;             // d-chunks per half tile
+  u32x4 ka[KH], kb[KH];
+#define IXT_KLOAD(DST_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = (F_) >> 1, h_ = (F_) & 1;                                                                     \
+    const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
+    if (ps_ * ppw < pages && j_ < kv_len && j_ != pos) {                                                          \
+      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, h_ * KH, lane % g.P);                         \
+      _Pragma("unroll") for (int d8 = 0; d8 < KH; ++d8) DST_[d8] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)d8 * g.P * 8); \
+    }                                                                                                             \
+  } while (0)
+  IXT_KLOAD(ka, 0);
+
+  // prologue: q heads, new k, new v of this kv head from the QKV slices (+ RoPE), K/V page write
+  {
+    const int page = prow[pos / g.P], tok = pos % g.P;
+    for (int idx = lane; idx < (GQ + 2) * half; idx += 64) {
+      const int which = idx / half, i = idx % half;   // 0..GQ-1: q heads, GQ: k, GQ+1: v
+      int col0;
+      if (which < GQ) col0 = (kvh * GQ + which) * HD;
+      else if (which == GQ) col0 = QN + kvh * HD;
+      else col0 = QN + KN + kvh * HD;
+      const float* pq = a.part + (size_t)r * a.ncols + col0;
+      float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
+      float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+      if (which <= GQ) {
+        const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
+        const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
+        const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
+        const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+        v1 = o1; v2 = o2;
+      }
+      if (which < GQ) {
+        qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+      } else if (which == GQ) {
+        kn[i] = v1; kn[half + i] = v2;
+        a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
+        a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+      } else {
+        vn[i] = v1; vn[half + i] = v2;
+        bf16_t* vd = a.vpages + vpage_off(g, page, kvh, tok);
+        vd[i] = f2bf(v1); vd[half + i] = f2bf(v2);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // LDS writes of this wave before its own cross-lane reads
+  __builtin_amdgcn_wave_barrier();
+
+  // scores: lane = key; one fma chain over d per (key, q head), continued across the two halves; running max per lane
+  float mx[GQ];
+#pragma unroll
+  for (int q = 0; q < GQ; ++q) mx[q] = -INFINITY;
+#define IXT_KHALF(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = (F_) >> 1, h_ = (F_) & 1;                                                                     \
+    const int j_ = (ps_ * ppw + lane / g.P) * g.P + lane % g.P;                                                   \
+    if (h_ == 0) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = 0.0f; }                                \
+    if (j_ < kv_len) {                                                                                            \
+      if (j_ == pos) {   /* the key this wave has just written: from LDS */                                       \
+        for (int d = h_ * (HD / 2); d < (h_ + 1) * (HD / 2); ++d) {                                               \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);  \
+        }                                                                                                         \
+      } else {                                                                                                    \
+        _Pragma("unroll") for (int d8 = 0; d8 < KH; ++d8) {                                                       \
+          const float kf[8] = {bflo(BUF_[d8].x), bfhi(BUF_[d8].x), bflo(BUF_[d8].y), bfhi(BUF_[d8].y),            \
+                               bflo(BUF_[d8].z), bfhi(BUF_[d8].z), bflo(BUF_[d8].w), bfhi(BUF_[d8].w)};           \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                        \
+            const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + d8) * 8);                 \
+            const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + d8) * 8 + 4);             \
+            float sacc = acc[q];                                                                                  \
+            sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);                   \
+            sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);                   \
+            sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);                   \
+            sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);                   \
+            acc[q] = sacc;                                                                                        \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
+      if (h_ == 1) {                                                                                              \
+        _Pragma("unroll") for (int q = 0; q < GQ; ++q) { ebuf[(size_t)q * g.Tmax + j_] = acc[q]; mx[q] = fmaxf(mx[q], acc[q]); } \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  {
+    const int ntile = (pages + ppw - 1) / ppw;
+    float acc[GQ];
+    for (int f = 0; f < 2 * ntile; f += 2) {
+      IXT_KLOAD(kb, f + 1);
+      IXT_KHALF(ka, f);
+      IXT_KLOAD(ka, f + 2);
+      IXT_KHALF(kb, f + 1);
+    }
+  }
+#undef IXT_KHALF
+#undef IXT_KLOAD
+
+  const int nb = g.P / 8;                                              // batches per page
+  const int ngrp = (pages + PPW - 1) / PPW;
+  const int nf = ngrp * nb;
+#define IXT_VLOAD(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    if (f_ < nf) {                                                                                                \
+      const int p_ = (f_ / nb) * PPW + tq, t0_ = (f_ % nb) * 8;                                                   \
+      if (p_ < pages) {                                                                                           \
+        const bf16_t* vp_ = a.vpages + vpage_off(g, prow[p_], kvh, t0_) + dc * 8;                                 \
+        const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                             \
+          if (u < nt_) BUF_[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)u * HD);                           \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+#define IXT_VBATCH(BUF_, F_)                                                                                      \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    const int p_ = (f_ / nb) * PPW + tq, bt_ = f_ % nb, t0_ = bt_ * 8;                                            \
+    if (bt_ == 0) { _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = 0.0f; }                                \
+    if (p_ < pages) {                                                                                             \
+      const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                          \
+      const float* pj_ = e + (size_t)p_ * g.P + t0_;                                                              \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                             \
+        if (u < nt_) {                                                                                            \
+          float vf[8] = {bflo(BUF_[u].x), bfhi(BUF_[u].x), bflo(BUF_[u].y), bfhi(BUF_[u].y),                      \
+                         bflo(BUF_[u].z), bfhi(BUF_[u].z), bflo(BUF_[u].w), bfhi(BUF_[u].w)};                     \
+          if (p_ * g.P + t0_ + u == pos) {   /* the token this wave has just written: its value comes from LDS */ \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) vf[j] = vn[dc * 8 + j];                                 \
+          }                                                                                                       \
+          const float pv = pj_[u];                                                                                \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);               \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (bt_ == nb - 1) {   /* group complete: its PPW/4 super-blocks, in order, onto the running total */         \
+      _Pragma("unroll") for (int sbl = 0; sbl < PPW / IXT_SB; ++sbl) {                                            \
+        float ss[8];                                                                                              \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = 0.0f;                                               \
+        _Pragma("unroll") for (int i = 0; i < IXT_SB; ++i) {                                                      \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = ss[j] + __shfl(acc[j], (sbl * IXT_SB + i) * LPP + dc, 64); \
+        }                                                                                                         \
+        if ((f_ / nb) * (PPW / IXT_SB) + sbl < nsb) {                                                             \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) total[j] = total[j] + ss[j];                              \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  for (int q = 0; q < GQ; ++q) {
+    float* e = ebuf + (size_t)q * g.Tmax;
+    u32x4 va[8], vb[8];
+    IXT_VLOAD(va, 0);
+    // max (order independent), exp, page sums in key order by the page's owner lane, l in page order, P
+    float m = mx[q];
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    for (int j = lane; j < kv_len; j += 64) e[j] = ixt_exp(e[j] - m);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (int p = lane; p < pages; p += 64) {
+      float sacc = 0.0f;
+      const int e1 = min((p + 1) * g.P, kv_len);
+      for (int j = p * g.P; j < e1; ++j) sacc = sacc + e[j];
+      psum[p] = sacc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float l = 0.0f;
+    for (int p = 0; p < pages; ++p) l = l + psum[p];
+    for (int j = lane; j < kv_len; j += 64) e[j] = rbf(e[j] / l);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float acc[8], total[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) total[j] = 0.0f;
+    for (int f = 0; f < nf; f += 2) {
+      IXT_VLOAD(vb, f + 1);
+      IXT_VBATCH(va, f);
+      if (f + 1 < nf) {
+        IXT_VLOAD(va, f + 2);
+        IXT_VBATCH(vb, f + 1);
+      }
+    }
+    if (tq == 0) {
+      u32x4 ov;
+      ov.x = pack2(f2bf(total[0]), f2bf(total[1])); ov.y = pack2(f2bf(total[2]), f2bf(total[3]));
+      ov.z = pack2(f2bf(total[4]), f2bf(total[5])); ov.w = pack2(f2bf(total[6]), f2bf(total[7]));
+      *reinterpret_cast<u32x4*>(a.out + xidx(r, (kvh * GQ + q) * HD + dc * 8, n_out)) = ov;
+    }
+    __builtin_amdgcn_wave_barrier();   // e / psum are reused by the next q head
+  }
+#undef IXT_VLOAD
+#undef IXT_VBATCH
+}
+
 // ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const int32_t* row_pos, const int32_t* row_active,
                                                       bf16_t* out, AttnGeom g, int kmajor) {

@@ -114,17 +114,19 @@ def test_tiny_batched_ragged(B, nprompts):
   run_pair(cfg, w, prompts, steps=40 if B <= 8 else (12 if B <= 40 else 5), check_logits=B <= 20)
 
 
+@pytest.mark.parametrize("wave_pairs", [1, 0])
 @pytest.mark.parametrize("B,nprompts", [(1, 1), (4, 3), (20, 13)])
-def test_tiny_one_launch_decode_attention(B, nprompts):
-  """The decode attention as ONE launch per layer (block = row x kv head; the default from rows x kv_heads >= 128) forced onto
-  small batches: ragged lengths, inactive slots, 2 query heads per kv head, page-boundary crossings during the 40 steps."""
+def test_tiny_one_launch_decode_attention(B, nprompts, wave_pairs):
+  """The decode attention as ONE launch per layer (the default from rows x kv_heads >= 128) forced onto small batches, in both
+  forms -- one wave per (row, kv head) without block barriers, and one block per pair: ragged lengths, inactive slots, 2 query
+  heads per kv head, page-boundary crossings during the 40 steps."""
   cfg = H.make_config(per_device_batch_size=float(B), pagedattn_num_pages=max(160, B * 10 + 1))
   w = H.synth.synth_weights(cfg, 5)
   prompts = []
   for s in range(nprompts):
     toks, _ = H.synth.synth_prompt(cfg.vocab_size, cfg.max_prefill_predict_length, 300 + s)
     prompts.append((toks, [32, 1, 9, 17, 8, 31, 16, 24][s % 8]))
-  run_pair(cfg, w, prompts, steps=40, options={"attn_fused_min_blocks": 1})
+  run_pair(cfg, w, prompts, steps=40, options={"attn_fused_min_blocks": 1, "attn_wave_pairs": wave_pairs})
 
 
 def test_audio_only_sampling_ranges():
@@ -165,7 +167,7 @@ def test_tiny_chunked_prefill():
   del eng
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("fused", [0, 1, 2])
 def test_head_dim_128_mha_page32(fused):
   """C2's attention geometry (head_dim 128, MHA, 32-token pages) on a small body; key ranges of up to 9 pages = 3 super-blocks,
   through the split kernels and through the one-launch decode attention."""
@@ -175,7 +177,7 @@ def test_head_dim_128_mha_page32(fused):
   w = H.synth.synth_weights(cfg, 4)
   p0 = H.synth.synth_prompt(cfg.vocab_size, 64, 1)
   p1 = H.synth.synth_prompt(cfg.vocab_size, 64, 2)
-  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"attn_fused_min_blocks": 1} if fused else None)
+  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"attn_fused_min_blocks": 1, "attn_wave_pairs": fused - 1} if fused else None)
 
 
 def test_release_and_reuse_slot():
