@@ -73,6 +73,9 @@ struct ixt_ctx {
   // timing
   bool timing = false;
   int attn_fused_min_blocks = 128;
+  // tiled GEMM form of the dot: from 128 rows and 150 blocks of 128 x 128 (at C2 / 256 rows: the 2048 x 14336 MLP kernel only; the
+  // 2048 x 6144 QKV kernel has 96 such blocks and measured slower than split-K, as did 64-column blocks)
+  int gemm_min_rows = 128, gemm_min_blocks = 150;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -436,6 +439,33 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   // as the weights.  Kept behind an option (default off): with 2 resident blocks per CU and a barrier pair per chain it measured
   // slightly SLOWER than split-K on the 2048 x 14336 and 2048 x 6144 kernels at 256 rows.  (Walking the chains inside k_dotb
   // was worse still: 102 vs 54 us.)
+  // Many rows x many columns: the tiled GEMM (128 rows x 128 or 64 columns x all of K per block, one slice) once it has enough blocks
+  {
+    const int zb = (R + 127) / 128;
+    static const int ct_env = env_int("IXT_GEMM_CT", 4);
+    const int ct = ct_env == 4 ? 4 : 2;
+    const int ncolg = (ntile + 2 * ct - 1) / (2 * ct);
+    if (!force_full && R >= c->gemm_min_rows && (long)ncolg * zb >= c->gemm_min_blocks && (size_t)R * N <= out_floats) {
+      const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (double)R * N * 4.0);
+      dim3 grid(((ncolg + 7) / 8) * 8 * zb, 1, 1);
+      const u32x4* xp = reinterpret_cast<const u32x4*>(x);
+      const u32x4* wp = reinterpret_cast<const u32x4*>(w);
+      const size_t lds = (size_t)2 * (4 * ct + 16) * 1024;
+#define GEMM(NT_)                                                                                                        \
+  do {                                                                                                                   \
+    if (ct == 4) hipLaunchKernelGGL((k_gemm<NT_, 4>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb);        \
+    else hipLaunchKernelGGL((k_gemm<NT_, 2>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb);                \
+  } while (0)
+      if (zb == 1) GEMM(true); else GEMM(false);
+#undef GEMM
+      timing_end(c, st, ti);
+      LAUNCHCHK();
+      res->slices = 1;
+      res->slice_stride = (size_t)R * N;
+      res->ntiles = ntile;
+      return IXT_OK;
+    }
+  }
   const int stream_min_blocks = c->dot_stream_min_blocks;
   if (!force_full && nrb == 4 && zblocks >= 2 && chains > 1 && chains <= 4 && (long)((ntile + 7) / 8) * zblocks >= stream_min_blocks &&
       (size_t)R * N <= out_floats) {
@@ -917,6 +947,14 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launch sequences embed the old choice
     c->graphs.clear();
     c->attn_fused_min_blocks = value;
+    return IXT_OK;
+  }
+  if (strcmp(name, "gemm_min_blocks") == 0 || strcmp(name, "gemm_min_rows") == 0) {
+    if (value < 1) return set_err(IXT_ERR_RANGE, "%s must be positive", name);
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+    c->graphs.clear();
+    if (name[9] == 'b') c->gemm_min_blocks = value; else c->gemm_min_rows = value;
     return IXT_OK;
   }
   if (strcmp(name, "attn_wave_pairs") == 0) {

@@ -314,6 +314,106 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
   }
 }
 
+// =====================================================================================================
+// Canonical DOT as a tiled GEMM, for many rows (>= 128) x many columns: block = 4 waves (2 x 2) = 128 rows x 128 columns x
+// ALL of K, wave = 64 x 64 (4 x 4 MFMA tiles: every weight fragment meets 4 activation fragments and vice versa, so a k-step
+// costs 8 LDS fragment reads for 16 MFMAs and the L2 -> CU traffic per MAC is a quarter of k_dotb's).  K is walked in chunks of
+// 64 (2 k-steps): the next chunk's 32 KiB (16 weight + 16 activation fragments) are fetched into registers while the current
+// one is consumed from LDS (2 stages, one barrier per chunk).  Every 512 k the accumulators are added to the totals
+// (t = t + chain(c), c ascending: the canonical order), so ONE f32 slice leaves the chip instead of `chains`.
+//   grid = ceil(N/128) * ceil(R/128) (row groups of the same columns are ids b, b + 8, ..: same XCD), block 256, LDS 64 KiB.
+// =====================================================================================================
+//   CT = column tiles per wave: 4 (block 128 x 128, LDS 64 KiB) or 2 (block 128 rows x 64 columns, LDS 48 KiB: twice the blocks,
+//   three per CU -- for matrices whose 128-column groups alone would leave CUs with a single block and one chunk in flight).
+template <bool NT, int CT>
+__global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+                                                 float* __restrict__ out, int ncolg, int zblocks) {
+  constexpr int NWF = 4 * CT;          // weight fragments per chunk (2 CT tiles x 2 k-steps)
+  constexpr int NF = NWF + 16;         // + 8 row blocks x 2 k-steps of activations
+  constexpr int NJ = NF / 4;           // fragments staged per thread and chunk
+  extern __shared__ __attribute__((aligned(16))) u32x4 st[];   // [2 stages][NF fragments][64 lanes]; f < NWF: weights (tile f>>1, k-step f&1), else activations
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int bx = blockIdx.x;
+  const int colg = (bx / (8 * zblocks)) * 8 + (bx & 7), rowg = (bx >> 3) % zblocks;
+  if (colg >= ncolg) return;                                    // whole block: no barrier is skipped
+  const int nsteps = K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;
+  const int nchunks = nsteps >> 1;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int r_in = lane & 15, cq = lane >> 4;
+  const u32x4* src[NJ];
+  bool ok[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int f = wave + 4 * j;
+    if (f < NWF) {
+      const int tile = colg * 2 * CT + (f >> 1);
+      ok[j] = tile < ntile;
+      src[j] = wt + ((size_t)(ok[j] ? tile : 0) * nsteps + (f & 1)) * 64 + lane;
+    } else {
+      const int rb = rowg * 8 + ((f - NWF) >> 1);
+      ok[j] = rb < nrbk;
+      src[j] = xt + ((size_t)(ok[j] ? rb : 0) * nsteps + (f & 1)) * 64 + lane;
+    }
+  }
+  u32x4 pre[NJ];
+#define IXT_GFETCH(CH_)                                                                              \
+  do {                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                 \
+      if (!ok[j]) pre[j] = u32x4(0);                                                                 \
+      else if (NT && wave + 4 * j < NWF) pre[j] = __builtin_nontemporal_load(src[j] + (size_t)(CH_) * 128); \
+      else pre[j] = src[j][(size_t)(CH_) * 128];                                                     \
+    }                                                                                                \
+  } while (0)
+#define IXT_GSTORE(STAGE_)                                                                           \
+  do {                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) st[((STAGE_) * NF + wave + 4 * j) * 64 + lane] = pre[j]; \
+  } while (0)
+  f32x4 acc[CT][4], tot[CT][4];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
+  IXT_GFETCH(0);
+  IXT_GSTORE(0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    if (ch + 1 < nchunks) IXT_GFETCH(ch + 1);
+    const u32x4* sb = st + (size_t)(ch & 1) * NF * 64;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[CT], xf[4];
+#pragma unroll
+      for (int i = 0; i < CT; ++i) wf[i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * 2 + ks) * 64 + lane]);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) xf[b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * 4 + b) * 2 + ks) * 64 + lane]);
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
+    }
+    if ((ch & 7) == 7 || ch + 1 == nchunks) {   // a 512-k chain is complete
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
+    }
+    if (ch + 1 < nchunks) IXT_GSTORE((ch + 1) & 1);
+    __syncthreads();
+  }
+#undef IXT_GFETCH
+#undef IXT_GSTORE
+#pragma unroll
+  for (int i = 0; i < CT; ++i) {
+    const int tile = colg * 2 * CT + wc * CT + i;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int row = (rowg * 8 + wr * 4 + b) * 16 + r_in;
+      if (tile < ntile && row < R)
+        *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[i][b][0], tot[i][b][1], tot[i][b][2], tot[i][b][3]);
+    }
+  }
+}
+
 // weights: row-major [K][ncols] (bf16 or f32) -> the tiled fragment layout of a [K][*] matrix, columns n_off..n_off+ncols
 template <typename T>
 __global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off) {

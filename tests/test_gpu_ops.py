@@ -65,6 +65,19 @@ def test_dot_streaming_kernel(ctx, R, K, N):
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_stream_min_blocks", 1 << 30))
 
 
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 256), (250, 1152, 256), (200, 2048, 144), (129, 640, 16)])
+def test_dot_gemm_kernel(ctx, R, K, N):
+  """Many rows: the tiled GEMM form of the canonical dot (128 x 128 x all of K per block, chain totals added on chip, one slice)
+  forced onto small shapes: ragged last row group / row block, a short last chain, partial column groups."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1))
+  try:
+    rng = np.random.default_rng(R + K + N)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
+
+
 @pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
 def test_dot_wide_exponents_and_zeros(ctx, spread, zero_frac):
   """The matrix-core arithmetic truncates small products against the largest one of each 8-k step: exercise wide exponent
