@@ -325,9 +325,12 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
 // =====================================================================================================
 //   CT = column tiles per wave: 4 (block 128 x 128, LDS 64 KiB) or 2 (block 128 rows x 64 columns, LDS 48 KiB: twice the blocks,
 //   three per CU -- for matrices whose 128-column groups alone would leave CUs with a single block and one chunk in flight).
-template <bool NT, int CT>
+//   EPI = 1: the greedy-sampling epilogue of k_unembed (rounded logits on request, one (max, first index) pair per row and per
+//   wave column of 16 CT columns into amax_*[row][2 ncolg]) -- the unembedding at >= 128 rows.
+template <bool NT, int CT, int EPI>
 __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
-                                                 float* __restrict__ out, int ncolg, int zblocks) {
+                                                 float* __restrict__ out, int ncolg, int zblocks, float* __restrict__ amax_val,
+                                                 int32_t* __restrict__ amax_idx, ColRanges cr) {
   constexpr int NWF = 4 * CT;          // weight fragments per chunk (2 CT tiles x 2 k-steps)
   constexpr int NF = NWF + 16;         // + 8 row blocks x 2 k-steps of activations
   constexpr int NJ = NF / 4;           // fragments staged per thread and chunk
@@ -402,6 +405,38 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, c
   }
 #undef IXT_GFETCH
 #undef IXT_GSTORE
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int row = (rowg * 8 + wr * 4 + b) * 16 + r_in;
+      float bv = -INFINITY;
+      int bi = 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < CT; ++i) {
+        const int tile = colg * 2 * CT + wc * CT + i;
+        if (tile < ntile) {
+          float v[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = rbf(tot[i][b][j]);
+          if (out != nullptr && row < R) *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (v[j] > bv && col_allowed(cr, tile * 16 + cq * 4 + j)) { bv = v[j]; bi = tile * 16 + cq * 4 + j; }   // ascending columns
+        }
+      }
+#pragma unroll
+      for (int off = 16; off < 64; off <<= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+      }
+      if (cq == 0 && row < R) {
+        amax_val[(size_t)row * (2 * ncolg) + colg * 2 + wc] = bv;
+        amax_idx[(size_t)row * (2 * ncolg) + colg * 2 + wc] = bi;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < CT; ++i) {
     const int tile = colg * 2 * CT + wc * CT + i;
