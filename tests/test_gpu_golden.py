@@ -100,3 +100,30 @@ def test_c2_batch_properties(c2_weights, B):
     pre, res = eng.prefill(params=params, padded_tokens=chunk, true_length=n, slot=1, existing_prefix=ep)
     done += n
   assert int(res.data[0, 0]) == int(out[steps, 0])
+
+
+def test_decode_harness_reproduces_tiny_golden(capsys):
+  """The CLI harness with the reference's call order (MaxText/decode.py:85-184 -> maxtext-indextts2_amd/decode.py): the seeded
+  synthetic prompt (seed 1234 = slot 0 of the tiny golden), random-init weights of seed 0, 64 generate calls; the printed ids are
+  the golden's slot 0, and with audio-only sampling every id maps to an audio code."""
+  import re
+  g = np.load(os.path.join(H.GOLDEN, "tiny_decode.npz"))
+  decode = H.importlib.import_module("maxtext-indextts2_amd.decode")
+  argv = ["decode", H.BASE_YML, "model_name=ixt-tiny", "attention=paged", "scan_layers=false", "per_device_batch_size=2",
+          "max_prefill_predict_length=32", "max_target_length=96", "pagedattn_num_pages=64", "pagedattn_tokens_per_page=8",
+          "ixt_synthetic_seed=0", "autoregressive_decode_assert=" + ",".join(str(int(t)) for t in g["tokens"][:4, 0])]
+  decode.main(argv)
+  out = capsys.readouterr().out
+  ids = [int(t) for t in re.search(r"generated ids: \[(.*?)\]", out).group(1).split(",")]
+  assert ids == [int(t) for t in g["tokens"][:65, 0]]
+  # audio-only sampling through the harness: ranges from a mapping file in the array form of the reference's JSON
+  VE = H.importlib.import_module("maxtext-indextts2_amd.vocab_expansion")
+  m = VE.AudioTokenMapping.from_rule(num_audio=600, low_slots=99, low_base=6, high_base=400, padded_rows_end=1024)   # a table that fits the 1024-row tiny vocabulary
+  import tempfile
+  with tempfile.TemporaryDirectory() as d:
+    path = os.path.join(d, "map.npz")
+    np.savez(path, audio_to_embedding=m.audio_to_embedding, embedding_rows=m.embedding_rows, embedding_audio_id=m.embedding_audio_id)
+    decode.main(argv[:-1] + ["ixt_audio_only_sampling=true", "audio_token_mapping_path=" + path])
+  out = capsys.readouterr().out
+  codes = [int(t) for t in re.search(r"audio codes: \[(.*?)\]", out).group(1).split(",")]
+  assert len(codes) == 65 and min(codes) >= 0 and max(codes) < 600
