@@ -664,7 +664,7 @@ static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr
     hipLaunchKernelGGL((k_attn_decode_w<HD, GQ>), dim3((npairs + 3) / 4), dim3(256), lds_w, st, da, npairs);
     return;
   }
-  const size_t lds = sizeof(float) * ((size_t)GQ * HD + 2 * HD + (size_t)GQ * g.Tmax + g.mpg + 8 + (size_t)g.nsb_max * HD);
+  const size_t lds = sizeof(float) * ((size_t)GQ * HD + 2 * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 8 + (size_t)g.nsb_max * HD);
   hipLaunchKernelGGL((k_attn_decode<HD, GQ>), dim3(R, g.nkv), dim3(256), lds, st, da);
 }
 
@@ -723,7 +723,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     }
     // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
     const int fused_min = c->attn_fused_min_blocks;
-    const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * c->geom.Tmax + c->geom.mpg + 8 + (size_t)c->geom.nsb_max * c->D);
+    const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
     if (decode && R * c->KV >= fused_min && fused_lds <= 64 * 1024) {
       const int ta = timing_begin(c, st, 0.0, 1);   // K/V bytes depend on the rows' lengths: the caller prices them
       TRY(launch_attention_fused(c, l, R, dr, st));

@@ -1014,8 +1014,9 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   float* kn = qs + GQ * HD;                     // [HD] new key (bf16-rounded, as f32)
   float* vn = kn + HD;                          // [HD] new value
   float* ebuf = vn + HD;                        // [GQ][Tmax] scores -> exps -> P
-  float* psum = ebuf + (size_t)GQ * g.Tmax;     // [mpg]
-  float* wred = psum + g.mpg;                   // [8]
+  const int tp = (g.Tmax + 3) & ~3;             // row pitch of ebuf: 16-byte aligned rows, and psum after them
+  float* psum = ebuf + (size_t)GQ * tp;         // [mpg]
+  float* wred = psum + ((g.mpg + 3) & ~3);        // [8]
   float* sbs = wred + 8;                        // [nsb_max][HD] super-block sums of the head being finished
   const int pos = a.row_pos[r];
   const int kv_len = pos + 1;
@@ -1101,7 +1102,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
           }                                                                                                       \
         }                                                                                                         \
       }                                                                                                           \
-      if (h_ == 1) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * g.Tmax + j_] = acc[q]; }     \
+      if (h_ == 1) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * tp + j_] = acc[q]; }     \
     }                                                                                                             \
   } while (0)
   {
@@ -1176,7 +1177,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     }                                                                                                             \
   } while (0)
   for (int q = 0; q < GQ; ++q) {
-    float* e = ebuf + (size_t)q * g.Tmax;
+    float* e = ebuf + (size_t)q * tp;
     u32x4 va[8], vb[8];
     IXT_VLOAD(va, 0);
     // max (order independent), exp, page sums in key order, l in page order, P
@@ -1189,15 +1190,31 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
     for (int j = tid; j < kv_len; j += 256) e[j] = ixt_exp(e[j] - m);
     __syncthreads();
+    // page sums in key order by the page's owner thread: the page's values are fetched 8 at a time (two 16-byte LDS reads in
+    // flight) and added one after the other -- same order as a scalar loop, a tenth of its LDS round trips
     for (int p = tid; p < pages; p += 256) {
       float sacc = 0.0f;
-      const int e1 = min((p + 1) * g.P, kv_len);
-      for (int j = p * g.P; j < e1; ++j) sacc = sacc + e[j];
+      const float* ep = e + (size_t)p * g.P;
+      const int n = min(g.P, kv_len - p * g.P);
+      int t0 = 0;
+      for (; t0 + 8 <= n; t0 += 8) {
+        const float4 x0 = *reinterpret_cast<const float4*>(ep + t0), x1 = *reinterpret_cast<const float4*>(ep + t0 + 4);
+        sacc = sacc + x0.x; sacc = sacc + x0.y; sacc = sacc + x0.z; sacc = sacc + x0.w;
+        sacc = sacc + x1.x; sacc = sacc + x1.y; sacc = sacc + x1.z; sacc = sacc + x1.w;
+      }
+      for (; t0 < n; ++t0) sacc = sacc + ep[t0];
       psum[p] = sacc;
     }
     __syncthreads();
     float l = 0.0f;
-    for (int p = 0; p < pages; ++p) l = l + psum[p];
+    {
+      int p = 0;
+      for (; p + 4 <= pages; p += 4) {
+        const float4 x0 = *reinterpret_cast<const float4*>(psum + p);
+        l = l + x0.x; l = l + x0.y; l = l + x0.z; l = l + x0.w;
+      }
+      for (; p < pages; ++p) l = l + psum[p];
+    }
     for (int j = tid; j < kv_len; j += 256) e[j] = rbf(e[j] / l);
     __syncthreads();
     float acc[8];
