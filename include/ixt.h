@@ -163,6 +163,8 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "attn_fused_min_blocks"  decode attention runs as one launch per layer once rows x kv_heads reaches this (default 128)
  *   "gemm_min_rows", "gemm_min_blocks"  a dot of at least this many rows (default 128) and 128 x 128 blocks (default 150) runs as
  *                            the tiled GEMM kernel (all of K per block, one f32 slice) instead of split-K
+ *   "gemm_split_min_blocks"  below gemm_min_blocks: the same tiles split over the 512-k chains (one slice per chain) once there are
+ *                            this many (tile, chain) blocks (default 300); otherwise the 64-row split-K kernel
  *   "unembed_gemm"           1 (default): from gemm_min_rows rows the unembedding runs on the tiled GEMM kernel with the sampling epilogue
  *   "attn_wave_pairs"        1: the one-launch decode attention gives each (row, kv head) pair to one wave, no block barriers;
  *                            0 (default, measured faster): one 256-thread block per pair

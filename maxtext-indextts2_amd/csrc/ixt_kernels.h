@@ -330,7 +330,9 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
 //   PF = chunks fetched ahead into registers (the LDS keeps 2 stages).  PF = 3 (96 KiB in flight per block) needs more than 256
 //   registers per lane, i.e. one wave per SIMD (__launch_bounds__(256, 1)); measured SLOWER than PF = 1 at two blocks per CU
 //   (decode step 5.68 vs 5.25 ms at 256 rows), so every launch uses PF = 1.
-template <bool NT, int CT, int EPI, int PF>
+//   SPLIT: blockIdx.y = chain: the block walks only the 8 chunks of its chain and writes slice [chain][R][N] (split-K for
+//   matrices with too few 128 x 128 blocks to fill the chip; still half of k_dotb's L2 traffic per MAC).
+template <bool NT, int CT, int EPI, int PF, bool SPLIT>
 __global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                  float* __restrict__ out, int ncolg, int zblocks, float* __restrict__ amax_val,
                                                  int32_t* __restrict__ amax_idx, ColRanges cr) {
@@ -381,19 +383,22 @@ __global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __r
   for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int b = 0; b < 4; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
+  const int chb = SPLIT ? (int)blockIdx.y * 8 : 0;              // chunk range of this block
+  const int che = SPLIT ? min(nchunks, chb + 8) : nchunks;
+  if (SPLIT) out += (size_t)blockIdx.y * R * N;
 #pragma unroll
-  for (int u = 0; u < PF; ++u) IXT_GFETCH(u, u);
+  for (int u = 0; u < PF; ++u) IXT_GFETCH(u, chb + u);
   IXT_GSTORE(0, 0);
   __syncthreads();
   // chunk ch: its register slot (ch % PF) is free (chunk ch went to LDS one iteration ago) -> fetch chunk ch + PF into it;
   // consume chunk ch from LDS stage ch & 1; move chunk ch + 1 (fetched PF - 1 iterations ago) to the other stage; barrier.
-  for (int ch0 = 0; ch0 < nchunks; ch0 += PF) {
+  for (int ch0 = chb; ch0 < che; ch0 += PF) {
 #pragma unroll
     for (int u = 0; u < PF; ++u) {
       const int ch = ch0 + u;
-      if (ch < nchunks) {
-        IXT_GFETCH(u, ch + PF);
-        const u32x4* sb = st + (size_t)(ch & 1) * NF * 64;
+      if (ch < che) {
+        if (ch + PF < che) IXT_GFETCH(u, ch + PF);
+        const u32x4* sb = st + (size_t)((ch - chb) & 1) * NF * 64;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           bf16x8 wf[CT], xf[4];
@@ -406,13 +411,13 @@ __global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __r
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
         }
-        if ((ch & 7) == 7 || ch + 1 == nchunks) {   // a 512-k chain is complete
+        if ((ch & 7) == 7 || ch + 1 == che) {   // a 512-k chain is complete
 #pragma unroll
           for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
         }
-        if (ch + 1 < nchunks) IXT_GSTORE((u + 1) % PF, (ch + 1) & 1);
+        if (ch + 1 < che) IXT_GSTORE((u + 1) % PF, (ch + 1 - chb) & 1);
         __syncthreads();
       }
     }

@@ -78,6 +78,20 @@ def test_dot_gemm_kernel(ctx, R, K, N):
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
 
 
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 128), (250, 1152, 64), (200, 2048, 80)])
+def test_dot_gemm_split_kernel(ctx, R, K, N):
+  """The tiled GEMM split over the chains (one slice per chain), forced onto small shapes; ragged rows, a short last chain."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1 << 30))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_split_min_blocks", 1))
+  try:
+    rng = np.random.default_rng(R + K + N + 1)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_split_min_blocks", 300))
+
+
 @pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
 def test_dot_wide_exponents_and_zeros(ctx, spread, zero_frac):
   """The matrix-core arithmetic truncates small products against the largest one of each 8-k step: exercise wide exponent
