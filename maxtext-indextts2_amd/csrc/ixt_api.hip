@@ -455,8 +455,8 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       const size_t lds = (size_t)2 * (4 * ct + 16) * 1024;
 #define GEMM(NT_)                                                                                                        \
   do {                                                                                                                   \
-    if (ct == 4) hipLaunchKernelGGL((k_gemm<NT_, 4, 0, 1, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});        \
-    else hipLaunchKernelGGL((k_gemm<NT_, 2, 0, 1, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});                \
+    if (ct == 4) hipLaunchKernelGGL((k_gemm<NT_, 4, 0, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});        \
+    else hipLaunchKernelGGL((k_gemm<NT_, 2, 0, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});                \
   } while (0)
       if (zb == 1) GEMM(true); else GEMM(false);
 #undef GEMM
@@ -477,8 +477,8 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       dim3 grid(((ncolg + 7) / 8) * 8 * zb, chains, 1);
       const u32x4* xp = reinterpret_cast<const u32x4*>(x);
       const u32x4* wp = reinterpret_cast<const u32x4*>(w);
-      if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 0, 1, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
-      else hipLaunchKernelGGL((k_gemm<false, 4, 0, 1, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+      if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 0, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+      else hipLaunchKernelGGL((k_gemm<false, 4, 0, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
       timing_end(c, st, ti);
       LAUNCHCHK();
       res->slices = chains;
@@ -545,8 +545,8 @@ static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out
     if ((size_t)R * 2 * ncolg > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
     const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (logits_out ? (double)R * N * 4.0 : 0.0));
     dim3 grid(((ncolg + 7) / 8) * 8 * zb, 1, 1);
-    if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 1, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
-    else hipLaunchKernelGGL((k_gemm<false, 4, 1, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
+    if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
+    else hipLaunchKernelGGL((k_gemm<false, 4, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
     timing_end(c, st, ti);
     hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, 2 * ncolg, argmax_out);
     LAUNCHCHK();

@@ -327,13 +327,11 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
 //   three per CU -- for matrices whose 128-column groups alone would leave CUs with a single block and one chunk in flight).
 //   EPI = 1: the greedy-sampling epilogue of k_unembed (rounded logits on request, one (max, first index) pair per row and per
 //   wave column of 16 CT columns into amax_*[row][2 ncolg]) -- the unembedding at >= 128 rows.
-//   PF = chunks fetched ahead into registers (the LDS keeps 2 stages).  PF = 3 (96 KiB in flight per block) needs more than 256
-//   registers per lane, i.e. one wave per SIMD (__launch_bounds__(256, 1)); measured SLOWER than PF = 1 at two blocks per CU
-//   (decode step 5.68 vs 5.25 ms at 256 rows), so every launch uses PF = 1.
 //   SPLIT: blockIdx.y = chain: the block walks only the 8 chunks of its chain and writes slice [chain][R][N] (split-K for
 //   matrices with too few 128 x 128 blocks to fill the chip; still half of k_dotb's L2 traffic per MAC).
-template <bool NT, int CT, int EPI, int PF, bool SPLIT>
-__global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+//   (Fetching 3 chunks ahead into registers -- one wave per SIMD, 512 registers -- was measured slower: 5.68 vs 5.25 ms per step.)
+template <bool NT, int CT, int EPI, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                  float* __restrict__ out, int ncolg, int zblocks, float* __restrict__ amax_val,
                                                  int32_t* __restrict__ amax_idx, ColRanges cr) {
   constexpr int NWF = 4 * CT;          // weight fragments per chunk (2 CT tiles x 2 k-steps)
@@ -363,20 +361,18 @@ __global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __r
       src[j] = xt + ((size_t)(ok[j] ? rb : 0) * nsteps + (f & 1)) * 64 + lane;
     }
   }
-  u32x4 pre[PF][NJ];
-#define IXT_GFETCH(SLOT_, CH_)                                                                       \
+  u32x4 pre[NJ];
+#define IXT_GFETCH(CH_)                                                                              \
   do {                                                                                               \
-    if ((CH_) < nchunks) {                                                                           \
-      _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                               \
-        if (!ok[j]) pre[SLOT_][j] = u32x4(0);                                                        \
-        else if (NT && wave + 4 * j < NWF) pre[SLOT_][j] = __builtin_nontemporal_load(src[j] + (size_t)(CH_) * 128); \
-        else pre[SLOT_][j] = src[j][(size_t)(CH_) * 128];                                            \
-      }                                                                                              \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) {                                                 \
+      if (!ok[j]) pre[j] = u32x4(0);                                                                 \
+      else if (NT && wave + 4 * j < NWF) pre[j] = __builtin_nontemporal_load(src[j] + (size_t)(CH_) * 128); \
+      else pre[j] = src[j][(size_t)(CH_) * 128];                                                     \
     }                                                                                                \
   } while (0)
-#define IXT_GSTORE(SLOT_, STAGE_)                                                                    \
+#define IXT_GSTORE(STAGE_)                                                                           \
   do {                                                                                               \
-    _Pragma("unroll") for (int j = 0; j < NJ; ++j) st[((STAGE_) * NF + wave + 4 * j) * 64 + lane] = pre[SLOT_][j]; \
+    _Pragma("unroll") for (int j = 0; j < NJ; ++j) st[((STAGE_) * NF + wave + 4 * j) * 64 + lane] = pre[j]; \
   } while (0)
   f32x4 acc[CT][4], tot[CT][4];
 #pragma unroll
@@ -386,41 +382,32 @@ __global__ __launch_bounds__(256, (PF > 1 ? 1 : 2)) void k_gemm(const u32x4* __r
   const int chb = SPLIT ? (int)blockIdx.y * 8 : 0;              // chunk range of this block
   const int che = SPLIT ? min(nchunks, chb + 8) : nchunks;
   if (SPLIT) out += (size_t)blockIdx.y * R * N;
-#pragma unroll
-  for (int u = 0; u < PF; ++u) IXT_GFETCH(u, chb + u);
-  IXT_GSTORE(0, 0);
+  IXT_GFETCH(chb);
+  IXT_GSTORE(0);
   __syncthreads();
-  // chunk ch: its register slot (ch % PF) is free (chunk ch went to LDS one iteration ago) -> fetch chunk ch + PF into it;
-  // consume chunk ch from LDS stage ch & 1; move chunk ch + 1 (fetched PF - 1 iterations ago) to the other stage; barrier.
-  for (int ch0 = chb; ch0 < che; ch0 += PF) {
+  for (int ch = chb; ch < che; ++ch) {
+    if (ch + 1 < che) IXT_GFETCH(ch + 1);
+    const u32x4* sb = st + (size_t)((ch - chb) & 1) * NF * 64;
 #pragma unroll
-    for (int u = 0; u < PF; ++u) {
-      const int ch = ch0 + u;
-      if (ch < che) {
-        if (ch + PF < che) IXT_GFETCH(u, ch + PF);
-        const u32x4* sb = st + (size_t)((ch - chb) & 1) * NF * 64;
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 wf[CT], xf[4];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          bf16x8 wf[CT], xf[4];
+      for (int i = 0; i < CT; ++i) wf[i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * 2 + ks) * 64 + lane]);
 #pragma unroll
-          for (int i = 0; i < CT; ++i) wf[i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * 2 + ks) * 64 + lane]);
+      for (int b = 0; b < 4; ++b) xf[b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * 4 + b) * 2 + ks) * 64 + lane]);
 #pragma unroll
-          for (int b = 0; b < 4; ++b) xf[b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * 4 + b) * 2 + ks) * 64 + lane]);
+      for (int i = 0; i < CT; ++i)
 #pragma unroll
-          for (int i = 0; i < CT; ++i)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
-        }
-        if ((ch & 7) == 7 || ch + 1 == che) {   // a 512-k chain is complete
-#pragma unroll
-          for (int i = 0; i < CT; ++i)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
-        }
-        if (ch + 1 < che) IXT_GSTORE((u + 1) % PF, (ch + 1 - chb) & 1);
-        __syncthreads();
-      }
+        for (int b = 0; b < 4; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
     }
+    if ((ch & 7) == 7 || ch + 1 == che) {   // a 512-k chain is complete
+#pragma unroll
+      for (int i = 0; i < CT; ++i)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
+    }
+    if (ch + 1 < che) IXT_GSTORE((ch + 1 - chb) & 1);
+    __syncthreads();
   }
 #undef IXT_GFETCH
 #undef IXT_GSTORE
