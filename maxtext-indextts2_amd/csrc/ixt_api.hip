@@ -756,7 +756,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
     TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
     TRY(launch_dot(c, c->xn, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
-    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
+    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();
     TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
     // residual + the next norm (the next layer's pre-attention norm, or the final norm when every row gets logits) in one launch

@@ -605,16 +605,32 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
 
 // =====================================================================================================
 // SwiGLU from partial slices (linears.py:449-464): part is [slices][R][2F] (wi_0 columns then wi_1).
-// grid = (ceil(F/256), R), block 256.
+// grid = (ceil(F/2048), R), block 256: a thread owns 8 consecutive features (two 16-byte loads per slice and operand, one
+// 16-byte store: 8 consecutive features of a row are one lane's fragment bytes in the dot kernel's x layout).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slices, size_t slice_stride, int F,
-                                                      bf16_t* out /*[R][F]*/) {
-  const int f = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
-  if (f >= F) return;
+                                                      bf16_t* out /*[R][F] in xidx layout*/) {
+  const int f0 = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y;
+  if (f0 >= F) return;
   const float* p = part + (size_t)r * 2 * F;
-  const float a = sum_slices<16>(p + f, slice_stride, slices);
-  const float b = sum_slices<16>(p + F + f, slice_stride, slices);
-  out[xidx(r, f, F)] = ixt_swiglu(rbf(a), rbf(b));   // x layout of the dot kernel
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a[j] = 0.0f; b[j] = 0.0f; }
+  for (int s = 0; s < slices; ++s) {   // slices added in order from 0 (sum_slices semantics)
+    const float* ps = p + (size_t)s * slice_stride;
+    const float4 a0 = *reinterpret_cast<const float4*>(ps + f0), a1 = *reinterpret_cast<const float4*>(ps + f0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(ps + F + f0), b1 = *reinterpret_cast<const float4*>(ps + F + f0 + 4);
+    a[0] = a[0] + a0.x; a[1] = a[1] + a0.y; a[2] = a[2] + a0.z; a[3] = a[3] + a0.w;
+    a[4] = a[4] + a1.x; a[5] = a[5] + a1.y; a[6] = a[6] + a1.z; a[7] = a[7] + a1.w;
+    b[0] = b[0] + b0.x; b[1] = b[1] + b0.y; b[2] = b[2] + b0.z; b[3] = b[3] + b0.w;
+    b[4] = b[4] + b1.x; b[5] = b[5] + b1.y; b[6] = b[6] + b1.z; b[7] = b[7] + b1.w;
+  }
+  bf16_t o[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = ixt_swiglu(rbf(a[j]), rbf(b[j]));
+  u32x4 ov;
+  ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+  *reinterpret_cast<u32x4*>(out + xidx(r, f0, F)) = ov;
 }
 
 __global__ __launch_bounds__(256) void k_swiglu(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
