@@ -231,8 +231,9 @@ def main():
     kv_layer = nums["kv_bytes_per_token"] / cfg.num_decoder_layers                 # K+V bytes per token per layer (8 192 at C2)
     att_bpl = ctx_sum * kv_layer + B * kv_layer                                    # read every cached key/value once + write the new one
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
+    for pmc in (os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}.json")):
+      if not os.path.exists(pmc):
+        continue
       try:
         pj = json.load(open(pmc))
         if pj.get("batch") == B and pj.get("model") == args.model:
