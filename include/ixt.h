@@ -165,6 +165,8 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *                            the tiled GEMM kernel (all of K per block, one f32 slice) instead of split-K
  *   "gemm_split_min_blocks"  below gemm_min_blocks: the same tiles split over the 512-k chains (one slice per chain) once there are
  *                            this many (tile, chain) blocks (default 300); otherwise the 64-row split-K kernel
+ *   "gemm_prefix_halves"     1: the full-K GEMM form runs as two blocks per tile (first half of the chains as a running total, second half
+ *                            chain by chain); 0 (default, measured faster): one block per tile
  *   "unembed_gemm"           1 (default): from gemm_min_rows rows the unembedding runs on the tiled GEMM kernel with the sampling epilogue
  *   "attn_wave_pairs"        1: the one-launch decode attention gives each (row, kv head) pair to one wave, no block barriers;
  *                            0 (default, measured faster): one 256-thread block per pair

@@ -76,6 +76,7 @@ struct ixt_ctx {
   // tiled GEMM form of the dot: from 128 rows and 150 blocks of 128 x 128 (at C2 / 256 rows: the 2048 x 14336 MLP kernel only; the
   // 2048 x 6144 QKV kernel has 96 such blocks and measured slower than split-K, as did 64-column blocks)
   int gemm_min_rows = 128, gemm_min_blocks = 150;
+  int gemm_prefix_halves = 0;   // measured at 256 rows on the MLP up-projection: decode step 5.39 vs 4.84 ms: off
   int gemm_split_min_blocks = 300;   // 128 x 128 x one-chain blocks (at C2 / 256 rows: the QKV and MLP-down kernels; +2.4 % end to end)
   int unembed_gemm = getenv("IXT_UNEMBED_GEMM") ? atoi(getenv("IXT_UNEMBED_GEMM")) : 1;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
@@ -455,14 +456,20 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       const size_t lds = (size_t)2 * (4 * ct + 16) * 1024;
 #define GEMM(NT_)                                                                                                        \
   do {                                                                                                                   \
-    if (ct == 4) hipLaunchKernelGGL((k_gemm<NT_, 4, 0, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});        \
-    else hipLaunchKernelGGL((k_gemm<NT_, 2, 0, false>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});                \
+    if (ct == 4) hipLaunchKernelGGL((k_gemm<NT_, 4, 0, 0>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});        \
+    else hipLaunchKernelGGL((k_gemm<NT_, 2, 0, 0>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});                \
   } while (0)
-      if (zb == 1) GEMM(true); else GEMM(false);
+      int slices_out = 1;
+      if (c->gemm_prefix_halves && ct == 4 && chains >= 2 && (size_t)(1 + chains - chains / 2) * R * N <= out_floats) {
+        grid.y = 2;   // first half of the chains as a running total, second half chain by chain
+        slices_out = 1 + chains - chains / 2;
+        if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 0, 2>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+        else hipLaunchKernelGGL((k_gemm<false, 4, 0, 2>), grid, dim3(256), lds, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+      } else if (zb == 1) GEMM(true); else GEMM(false);
 #undef GEMM
       timing_end(c, st, ti);
       LAUNCHCHK();
-      res->slices = 1;
+      res->slices = slices_out;
       res->slice_stride = (size_t)R * N;
       res->ntiles = ntile;
       return IXT_OK;
@@ -477,8 +484,8 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
       dim3 grid(((ncolg + 7) / 8) * 8 * zb, chains, 1);
       const u32x4* xp = reinterpret_cast<const u32x4*>(x);
       const u32x4* wp = reinterpret_cast<const u32x4*>(w);
-      if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 0, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
-      else hipLaunchKernelGGL((k_gemm<false, 4, 0, true>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+      if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 0, 1>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
+      else hipLaunchKernelGGL((k_gemm<false, 4, 0, 1>), grid, dim3(256), (size_t)64 * 1024, st, xp, wp, K, N, R, out, ncolg, zb, (float*)nullptr, (int32_t*)nullptr, ColRanges{});
       timing_end(c, st, ti);
       LAUNCHCHK();
       res->slices = chains;
@@ -545,8 +552,8 @@ static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out
     if ((size_t)R * 2 * ncolg > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
     const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (logits_out ? (double)R * N * 4.0 : 0.0));
     dim3 grid(((ncolg + 7) / 8) * 8 * zb, 1, 1);
-    if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
-    else hipLaunchKernelGGL((k_gemm<false, 4, 1, false>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
+    if (zb == 1) hipLaunchKernelGGL((k_gemm<true, 4, 1, 0>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
+    else hipLaunchKernelGGL((k_gemm<false, 4, 1, 0>), grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(yT), reinterpret_cast<const u32x4*>(c->logits_w), K, N, R, logits_out, ncolg, zb, c->amax_val, c->amax_idx, c->sample_cols);
     timing_end(c, st, ti);
     hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, 2 * ncolg, argmax_out);
     LAUNCHCHK();
@@ -980,6 +987,13 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launch sequences embed the old choice
     c->graphs.clear();
     c->attn_fused_min_blocks = value;
+    return IXT_OK;
+  }
+  if (strcmp(name, "gemm_prefix_halves") == 0) {
+    HIPCHK(hipDeviceSynchronize());
+    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
+    c->graphs.clear();
+    c->gemm_prefix_halves = value ? 1 : 0;
     return IXT_OK;
   }
   if (strcmp(name, "gemm_split_min_blocks") == 0) {

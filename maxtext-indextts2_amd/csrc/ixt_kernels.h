@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256, 2) void k_unembed(const u32x4* __restrict__ xt
 //   SPLIT: blockIdx.y = chain: the block walks only the 8 chunks of its chain and writes slice [chain][R][N] (split-K for
 //   matrices with too few 128 x 128 blocks to fill the chip; still half of k_dotb's L2 traffic per MAC).
 //   (Fetching 3 chunks ahead into registers -- one wave per SIMD, 512 registers -- was measured slower: 5.68 vs 5.25 ms per step.)
-template <bool NT, int CT, int EPI, bool SPLIT>
+//   SPLIT = 2 (prefix halves): blockIdx.y = 0 walks the first half of the chains and writes their running total as slice 0;
+//   blockIdx.y = 1 walks the second half and writes every chain as its own slice (1, 2, ..): summed in slice order this is still
+//   ((0 + c0) + c1) + c2 + c3, twice the blocks of the full-K form for one or two extra slices.
+template <bool NT, int CT, int EPI, int SPLIT>
 __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                  float* __restrict__ out, int ncolg, int zblocks, float* __restrict__ amax_val,
                                                  int32_t* __restrict__ amax_idx, ColRanges cr) {
@@ -379,9 +382,11 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, c
   for (int i = 0; i < CT; ++i)
 #pragma unroll
     for (int b = 0; b < 4; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
-  const int chb = SPLIT ? (int)blockIdx.y * 8 : 0;              // chunk range of this block
-  const int che = SPLIT ? min(nchunks, chb + 8) : nchunks;
-  if (SPLIT) out += (size_t)blockIdx.y * R * N;
+  const int hchains = ((nchunks + 7) >> 3) >> 1;                // SPLIT 2: chains of the first half
+  const int chb = SPLIT == 1 ? (int)blockIdx.y * 8 : (SPLIT == 2 && blockIdx.y == 1) ? hchains * 8 : 0;   // chunk range of this block
+  const int che = SPLIT == 1 ? min(nchunks, chb + 8) : (SPLIT == 2 && blockIdx.y == 0) ? hchains * 8 : nchunks;
+  if (SPLIT == 1) out += (size_t)blockIdx.y * R * N;
+  const bool per_chain = SPLIT == 2 && blockIdx.y == 1;         // every chain of this block is its own slice
   IXT_GFETCH(chb);
   IXT_GSTORE(0);
   __syncthreads();
@@ -401,16 +406,32 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, c
         for (int b = 0; b < 4; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
     }
     if ((ch & 7) == 7 || ch + 1 == che) {   // a 512-k chain is complete
+      if (SPLIT == 2 && per_chain) {
+        float* so = out + (size_t)(1 + (ch >> 3) - hchains) * R * N;
 #pragma unroll
-      for (int i = 0; i < CT; ++i)
+        for (int i = 0; i < CT; ++i) {
+          const int tile = colg * 2 * CT + wc * CT + i;
 #pragma unroll
-        for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
+          for (int b = 0; b < 4; ++b) {
+            const int row = (rowg * 8 + wr * 4 + b) * 16 + r_in;
+            if (tile < ntile && row < R)
+              *reinterpret_cast<float4*>(so + (size_t)row * N + tile * 16 + cq * 4) = make_float4(acc[i][b][0], acc[i][b][1], acc[i][b][2], acc[i][b][3]);
+            acc[i][b] = f32x4(0.0f);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < CT; ++i)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
+      }
     }
     if (ch + 1 < che) IXT_GSTORE((ch + 1 - chb) & 1);
     __syncthreads();
   }
 #undef IXT_GFETCH
 #undef IXT_GSTORE
+  if (SPLIT == 2 && per_chain) return;
   if constexpr (EPI == 1) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {

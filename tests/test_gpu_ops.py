@@ -78,6 +78,20 @@ def test_dot_gemm_kernel(ctx, R, K, N):
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
 
 
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 128), (250, 1536, 64), (200, 2048, 80), (130, 512, 16)])
+def test_dot_gemm_prefix_halves(ctx, R, K, N):
+  """The tiled GEMM with the chains in two halves: first half as a running total (slice 0), second half chain by chain."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_prefix_halves", 1))
+  try:
+    rng = np.random.default_rng(R + K + N + 2)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_prefix_halves", 0))
+
+
 @pytest.mark.parametrize("R,K,N", [(128, 1024, 128), (250, 1152, 64), (200, 2048, 80)])
 def test_dot_gemm_split_kernel(ctx, R, K, N):
   """The tiled GEMM split over the chains (one slice per chain), forced onto small shapes; ragged rows, a short last chain."""
