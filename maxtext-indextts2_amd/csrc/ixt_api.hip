@@ -677,29 +677,30 @@ static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStre
 }
 
 template <int HD, int GQ>
-static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr, hipStream_t st) {
+static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr, bool newtok, hipStream_t st) {
   const AttnGeom& g = c->geom;
   DecAttnArgs da;
   da.part = c->part; da.slices = dr.slices; da.slice_stride = dr.slice_stride; da.ncols = c->NQKV;
   da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
   da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
   da.kpages = c->kpages + (size_t)layer * c->layer_page_elems; da.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
-  da.out = c->ao; da.g = g;
+  da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
   const size_t lds_w = 4 * sizeof(float) * ((size_t)(GQ + 2) * HD + (size_t)GQ * g.Tmax + g.mpg);
-  if (c->attn_wave_pairs && lds_w <= 64 * 1024) {   // one wave per (row, kv head), no block barriers
+  if (newtok && c->attn_wave_pairs && lds_w <= 64 * 1024) {   // one wave per (row, kv head), no block barriers
     const int npairs = R * g.nkv;
     hipLaunchKernelGGL((k_attn_decode_w<HD, GQ>), dim3((npairs + 3) / 4), dim3(256), lds_w, st, da, npairs);
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)GQ * HD + 2 * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 8 + (size_t)g.nsb_max * HD);
-  hipLaunchKernelGGL((k_attn_decode<HD, GQ>), dim3(R, g.nkv), dim3(256), lds, st, da);
+  if (newtok) hipLaunchKernelGGL((k_attn_decode<HD, GQ, true>), dim3(R, g.nkv), dim3(256), lds, st, da);
+  else hipLaunchKernelGGL((k_attn_decode<HD, GQ, false>), dim3(R, g.nkv), dim3(256), lds, st, da);
 }
 
 // decode rows, enough (row, kv head) pairs to fill the chip: the whole attention in one launch (writes c->ao)
-static int launch_attention_fused(ixt_ctx* c, int layer, int R, const DotResult& qkv, hipStream_t st) {
+static int launch_attention_fused(ixt_ctx* c, int layer, int R, const DotResult& qkv, bool newtok, hipStream_t st) {
 #define ATT(HD_, GQ_)                                                                             \
   if (c->D == HD_ && c->GQ == GQ_) {                                                              \
-    launch_decode_attn<HD_, GQ_>(c, layer, R, qkv, st);                                           \
+    launch_decode_attn<HD_, GQ_>(c, layer, R, qkv, newtok, st);                                   \
     LAUNCHCHK();                                                                                  \
     return IXT_OK;                                                                                \
   }
@@ -751,9 +752,9 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
     const int fused_min = c->attn_fused_min_blocks;
     const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
-    if (decode && R * c->KV >= fused_min && fused_lds <= 64 * 1024) {
-      const int ta = timing_begin(c, st, 0.0, 1);   // K/V bytes depend on the rows' lengths: the caller prices them
-      TRY(launch_attention_fused(c, l, R, dr, st));
+    if (R * c->KV >= fused_min && fused_lds <= 64 * 1024) {   // decode rows, and prefill rows after k_qkv_finalize
+      const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;   // K/V bytes depend on the rows' lengths: the caller prices them
+      TRY(launch_attention_fused(c, l, R, dr, decode, st));
       timing_end(c, st, ta);
     } else {
       TRY(launch_attention_partials(c, l, R, len_hint, dr, decode, st));

@@ -1040,9 +1040,12 @@ struct DecAttnArgs {
   bf16_t* kpages; bf16_t* vpages;
   bf16_t* out;        // [R][nq*hd] in xidx layout
   AttnGeom g;
+  const bf16_t* qbuf; // NEWTOK = false: [R][nq][hd] finalised queries
 };
 
-template <int HD, int GQ>
+// NEWTOK = true: decode rows (the row's own new token is finalised here: QKV slices -> RoPE -> pages, and read back from LDS).
+// NEWTOK = false: prefill rows: q comes from qbuf and every key / value from the pages (k_qkv_finalize ran before this launch).
+template <int HD, int GQ, bool NEWTOK>
 __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const AttnGeom& g = a.g;
@@ -1079,13 +1082,14 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   do {                                                                                                            \
     const int ps_ = wave + 4 * ((F_) >> 1), h_ = (F_) & 1;                                                        \
     const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
-    if (ps_ * ppw < pages && j_ < kv_len && j_ != pos) {                                                          \
+    if (ps_ * ppw < pages && j_ < kv_len && (!NEWTOK || j_ != pos)) {                                             \
       const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, h_ * KH, lane % g.P);                         \
       _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
     }                                                                                                             \
   } while (0)
   IXT_KLOAD(ka, 0);
 
+  if constexpr (NEWTOK) {
   // prologue: q heads, new k, new v of this kv head from the QKV slices (+ RoPE), K/V page write
   for (int idx = tid; idx < (GQ + 2) * half; idx += 256) {
     const int which = idx / half, i = idx % half;   // 0..GQ-1: q heads, GQ: k, GQ+1: v
@@ -1116,6 +1120,10 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
       vd[i] = f2bf(v1); vd[half + i] = f2bf(v2);
     }
   }
+  } else {
+    const bf16_t* qsrc = a.qbuf + ((size_t)r * g.nq + kvh * GQ) * HD;
+    for (int i = tid; i < GQ * HD; i += 256) qs[i] = bf2f(qsrc[i]);
+  }
   __syncthreads();
 
   // scores: lane = key; one fma chain over d per (key, q head), continued across the two halves
@@ -1125,7 +1133,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     const int j_ = (ps_ * ppw + lane / g.P) * g.P + lane % g.P;                                                   \
     if (h_ == 0) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = 0.0f; }                                \
     if (j_ < kv_len) {                                                                                            \
-      if (j_ == pos) {   /* the key this block has just written: from LDS */                                      \
+      if (NEWTOK && j_ == pos) {   /* the key this block has just written: from LDS */                            \
         for (int d = h_ * (HD / 2); d < (h_ + 1) * (HD / 2); ++d) {                                               \
           _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = __builtin_fmaf(qs[q * HD + d], kn[d], acc[q]);  \
         }                                                                                                         \
@@ -1196,7 +1204,7 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
         if (u < nt_) {                                                                                            \
           float vf[8] = {bflo(BUF_[u].x), bfhi(BUF_[u].x), bflo(BUF_[u].y), bfhi(BUF_[u].y),                      \
                          bflo(BUF_[u].z), bfhi(BUF_[u].z), bflo(BUF_[u].w), bfhi(BUF_[u].w)};                     \
-          if (p_ * g.P + t0_ + u == pos) {   /* the token this block has just written: its value comes from LDS */ \
+          if (NEWTOK && p_ * g.P + t0_ + u == pos) {   /* the token this block has just written: its value comes from LDS */ \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) vf[j] = vn[dc * 8 + j];                                 \
           }                                                                                                       \
           const float pv = pj_[u];                                                                                \
