@@ -55,7 +55,7 @@ struct ixt_ctx {
   // tables / pools / state
   bf16_t *rope_sin = nullptr, *rope_cos = nullptr;
   std::vector<uint16_t> rope_sin_h, rope_cos_h;
-  bf16_t *kpages = nullptr, *vpages = nullptr;
+  std::vector<bf16_t*> kpages_l, vpages_l;   // one allocation per layer: [page][kv_head][...]
   size_t layer_page_elems = 0;
   PageStateDev ps{};
   // workspaces
@@ -183,9 +183,15 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
   // page pools
   x->layer_page_elems = (size_t)c.pagedattn_num_pages * x->KV * x->P * x->D;
-  A(dmalloc(x, &x->kpages, x->layer_page_elems * L));
-  A(dmalloc(x, &x->vpages, x->layer_page_elems * L));
-  if (hipMemset(x->kpages, 0, x->layer_page_elems * L * 2) != hipSuccess || hipMemset(x->vpages, 0, x->layer_page_elems * L * 2) != hipSuccess)
+  x->kpages_l.assign(L, nullptr);
+  x->vpages_l.assign(L, nullptr);
+  bool zero_ok = true;
+  for (int l = 0; l < L; ++l) {
+    A(dmalloc(x, &x->kpages_l[l], x->layer_page_elems));
+    A(dmalloc(x, &x->vpages_l[l], x->layer_page_elems));
+    zero_ok = zero_ok && hipMemset(x->kpages_l[l], 0, x->layer_page_elems * 2) == hipSuccess && hipMemset(x->vpages_l[l], 0, x->layer_page_elems * 2) == hipSuccess;
+  }
+  if (!zero_ok)
     return fail(set_err(IXT_ERR_HIP, "page pool memset failed"));
   // page state
   PageStateDev& s = x->ps;
@@ -590,7 +596,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
   int nsplit = (pages_hint + 4 * ppw - 1) / (4 * ppw);
   if (nsplit < 1) nsplit = 1;
   ScoreArgs sa;
-  sa.qbuf = qbuf; sa.kpages = c->kpages + (size_t)layer * c->layer_page_elems;
+  sa.qbuf = qbuf; sa.kpages = c->kpages_l[layer];
   sa.row_slot = c->row_slot; sa.row_pos = c->row_pos; sa.row_active = c->row_active; sa.page_map = c->ps.page_map;
   sa.scores = c->scores; sa.g = g;
   hipLaunchKernelGGL((k_attn_scores<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, sa);
@@ -598,7 +604,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
   int nchunk = (nsb_hint + 3) / 4;
   if (nchunk < 1) nchunk = 1;
   PvArgs pa;
-  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
   pa.pvpart = c->pvpart; pa.g = g;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
@@ -639,14 +645,14 @@ static void launch_front_pv(ixt_ctx* c, int layer, int R, int len_hint, const Do
   fa.part = c->part; fa.slices = dr.slices; fa.slice_stride = dr.slice_stride; fa.ncols = c->NQKV;
   fa.row_slot = c->row_slot; fa.row_pos = c->row_pos; fa.row_active = c->row_active; fa.page_map = c->ps.page_map;
   fa.rope_sin = c->rope_sin; fa.rope_cos = c->rope_cos;
-  fa.kpages = c->kpages + (size_t)layer * c->layer_page_elems; fa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  fa.kpages = c->kpages_l[layer]; fa.vpages = c->vpages_l[layer];
   fa.scores = c->scores; fa.g = g;
   hipLaunchKernelGGL((k_attn_front_decode<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, fa);
   const int nsb_hint = (pages_hint + IXT_SB - 1) / IXT_SB;
   int nchunk = (nsb_hint + 3) / 4;
   if (nchunk < 1) nchunk = 1;
   PvArgs pa;
-  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
   pa.pvpart = c->pvpart; pa.g = g;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
@@ -661,7 +667,7 @@ static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStre
   int nsplit = (pages_hint + 4 * ppw - 1) / (4 * ppw);
   if (nsplit < 1) nsplit = 1;
   ScoreArgs sa;
-  sa.qbuf = c->qbuf; sa.kpages = c->kpages + (size_t)layer * c->layer_page_elems;
+  sa.qbuf = c->qbuf; sa.kpages = c->kpages_l[layer];
   sa.row_slot = c->row_slot; sa.row_pos = c->row_pos; sa.row_active = c->row_active; sa.page_map = c->ps.page_map;
   sa.scores = c->scores; sa.g = g;
   hipLaunchKernelGGL((k_attn_scores<HD, GQ>), dim3(R, g.nkv, nsplit), dim3(256), 0, st, sa);
@@ -669,7 +675,7 @@ static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStre
   int nchunk = (nsb_hint + 3) / 4;
   if (nchunk < 1) nchunk = 1;
   PvArgs pa;
-  pa.scores = c->scores; pa.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
   pa.pvpart = c->pvpart; pa.g = g;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
@@ -683,7 +689,7 @@ static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr
   da.part = c->part; da.slices = dr.slices; da.slice_stride = dr.slice_stride; da.ncols = c->NQKV;
   da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
   da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
-  da.kpages = c->kpages + (size_t)layer * c->layer_page_elems; da.vpages = c->vpages + (size_t)layer * c->layer_page_elems;
+  da.kpages = c->kpages_l[layer]; da.vpages = c->vpages_l[layer];
   da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
   const size_t lds_w = 4 * sizeof(float) * ((size_t)(GQ + 2) * HD + (size_t)GQ * g.Tmax + g.mpg);
   if (newtok && c->attn_wave_pairs && lds_w <= 64 * 1024) {   // one wave per (row, kv head), no block barriers
@@ -744,7 +750,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
       qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
       qa.rope_sin = c->rope_sin; qa.rope_cos = c->rope_cos; qa.qbuf = c->qbuf;
-      qa.kpages = c->kpages + (size_t)l * c->layer_page_elems; qa.vpages = c->vpages + (size_t)l * c->layer_page_elems;
+      qa.kpages = c->kpages_l[l]; qa.vpages = c->vpages_l[l];
       qa.g = c->geom;
       hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
       LAUNCHCHK();
@@ -924,7 +930,7 @@ extern "C" int ixt_op_kv_write(ixt_ctx* c, int layer, const uint16_t* k, const u
                                const int32_t* row_active, int R, void* stream) {
   if (!c || !k || !v || layer < 0 || layer >= c->L || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipLaunchKernelGGL(k_kv_write, dim3(R, c->KV), dim3(c->D), 0, (hipStream_t)stream, k, v, row_slot, row_pos, row_active, c->ps.page_map,
-                     c->kpages + (size_t)layer * c->layer_page_elems, c->vpages + (size_t)layer * c->layer_page_elems, c->geom);
+                     c->kpages_l[layer], c->vpages_l[layer], c->geom);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -950,8 +956,8 @@ extern "C" int ixt_op_unembed_argmax(ixt_ctx* c, const uint16_t* y, int R, float
 extern "C" int ixt_kv_gather(ixt_ctx* c, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream) {
   if (!c || !k_out || !v_out || layer < 0 || layer >= c->L || length <= 0 || length > c->Tmax) return set_err(IXT_ERR_INVALID, "bad argument");
   TRY(check_slot(c, slot));
-  hipLaunchKernelGGL(k_kv_gather, dim3(length, c->KV), dim3(c->D), 0, (hipStream_t)stream, c->kpages + (size_t)layer * c->layer_page_elems,
-                     c->vpages + (size_t)layer * c->layer_page_elems, c->ps.page_map, slot, c->geom, k_out, v_out);
+  hipLaunchKernelGGL(k_kv_gather, dim3(length, c->KV), dim3(c->D), 0, (hipStream_t)stream, c->kpages_l[layer],
+                     c->vpages_l[layer], c->ps.page_map, slot, c->geom, k_out, v_out);
   LAUNCHCHK();
   return IXT_OK;
 }
