@@ -180,10 +180,11 @@ def test_head_dim_128_mha_page32(fused):
   run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"attn_fused_min_blocks": 1, "attn_wave_pairs": fused - 1} if fused else None)
 
 
+@pytest.mark.parametrize("hd", [64, 128])
 @pytest.mark.parametrize("fused", [0, 1, 2])
-def test_four_query_heads_per_kv_head(fused):
-  """GQA with 4 query heads per kv head (8 query / 2 kv heads of 64): split kernels, one-launch block form, one-launch wave form."""
-  cfg = H.make_config(base_emb_dim=256, base_num_query_heads=8, base_num_kv_heads=2, head_dim=64, base_mlp_dim=384,
+def test_four_query_heads_per_kv_head(fused, hd):
+  """GQA with 4 query heads per kv head (8 query / 2 kv heads of 64 or 128): split kernels, one-launch block form, one-launch wave form."""
+  cfg = H.make_config(base_emb_dim=256, base_num_query_heads=8, base_num_kv_heads=2, head_dim=hd, base_mlp_dim=384,
                       base_num_decoder_layers=2, vocab_size=1024, model_name="default", per_device_batch_size=3.0,
                       max_prefill_predict_length=32, max_target_length=96, pagedattn_tokens_per_page=16, pagedattn_num_pages=32)
   w = H.synth.synth_weights(cfg, 11)
