@@ -240,7 +240,7 @@ def main():
           traffic, traffic_src = pj["hbm_bytes_per_launch"], pj.get("source")
       except Exception:  # pylint: disable=broad-except
         pass
-    dot = {"kernel": "k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
+    dot = {"kernel": "k_gemm / k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
            "achieved": dot_bpl / (dot_us * 1e-6) / 1e9 if dot_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": dot_us, "launches": dot_n,
            "algorithmic_bytes_per_launch": dot_bpl, "us_per_step": dot_us * dot_n / nmeas}
     att = {"kernel": "k_attn_decode (one launch per layer: QKV finalize, scores, softmax, PV over the paged KV cache)", "bound": "hbm",
