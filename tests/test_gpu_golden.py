@@ -169,3 +169,35 @@ def test_expanded_checkpoint_end_to_end(tmp_path):
       orc.release_pages(0)
     finally:
       orc.set_sampling_ranges([])
+
+
+@pytest.mark.skipif(os.environ.get("IXT_SOAK") != "1", reason="slow (about 10 minutes of oracle time): set IXT_SOAK=1")
+def test_c2_many_rows_soak(c2_weights):
+  """Full-size model, 130 utterances (two GEMM row groups, the second one 2 rows): tiled GEMM kernels (full-K, split, sampling
+  epilogue) at the real matrix shapes against the oracle, 10 decode steps after ragged short prompts."""
+  g, w = c2_weights
+  B = 130
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=float(B), max_prefill_predict_length=64, max_target_length=128,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=B * 4 + 1)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  firsts, pres, opres = [], [], []
+  for s in range(B):
+    toks, _ = H.synth.synth_prompt(cfg.vocab_size, 64, 5000 + s)
+    tl = 8 + (s * 7) % 40
+    pre, r = eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=s)
+    opre, orr = orc.prefill(toks, tl, slot=s)
+    assert int(r.data[0, 0]) == int(orr[0, 0]), s
+    pres.append(pre)
+    opres.append(opre)
+    if s % 10 == 0:
+      print("soak: prefilled slot", s, flush=True)   # (run with -s: a silent GPU job is taken to be hung)
+  ds, ods = eng.init_decode_state(), orc.init_decode_state()
+  for s in range(B):
+    ds = eng.insert(pres[s], ds, s)
+    ods = orc.insert(opres[s], ods, s)
+  for i in range(10):
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods)
+    assert np.array_equal(r.data.cpu().numpy(), orr), i
+    print("soak: decode step", i, "ok", flush=True)
