@@ -557,6 +557,8 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
   const bf16_t* src = nullptr;
   if (MODE == 0) src = a.embedding + (size_t)a.tokens[r] * E;
   if (MODE == 1 || MODE == 2) src = a.h_in + (size_t)r * E;
+  // this thread's first scale chunk: fetched now, so that it is not one more memory round trip after the barrier
+  const u32x4 sv_first = (a.scale != nullptr && tid < nch) ? *reinterpret_cast<const u32x4*>(a.scale + tid * 8) : u32x4(0);
   for (int it = 0; it * 4 < nblk; ++it) {
     const int b = it * 4 + wave;
     const int ch = b * 64 + lane;
@@ -612,7 +614,7 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
   const float mean = total / (float)E;
   const float rs = 1.0f / sqrtf(mean + a.eps);
   for (int ch = tid; ch < nch; ch += 256) {
-    const u32x4 sv = *reinterpret_cast<const u32x4*>(a.scale + ch * 8);
+    const u32x4 sv = ch == tid ? sv_first : *reinterpret_cast<const u32x4*>(a.scale + ch * 8);
     const float sc[8] = {bflo(sv.x), bfhi(sv.x), bflo(sv.y), bfhi(sv.y), bflo(sv.z), bfhi(sv.z), bflo(sv.w), bfhi(sv.w)};
     bf16_t o[8];
 #pragma unroll
