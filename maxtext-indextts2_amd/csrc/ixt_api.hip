@@ -698,8 +698,8 @@ static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr
     return;
   }
   const size_t lds = sizeof(float) * ((size_t)GQ * HD + 2 * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 8 + (size_t)g.nsb_max * HD);
-  if (newtok) hipLaunchKernelGGL((k_attn_decode<HD, GQ, true>), dim3(R, g.nkv), dim3(256), lds, st, da);
-  else hipLaunchKernelGGL((k_attn_decode<HD, GQ, false>), dim3(R, g.nkv), dim3(256), lds, st, da);
+  if (newtok) hipLaunchKernelGGL((k_attn_decode<HD, GQ, true>), dim3(g.nkv, R), dim3(256), lds, st, da);
+  else hipLaunchKernelGGL((k_attn_decode<HD, GQ, false>), dim3(g.nkv, R), dim3(256), lds, st, da);
 }
 
 // decode rows, enough (row, kv head) pairs to fill the chip: the whole attention in one launch (writes c->ao)

@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
 //      partial round trip through HBM, no per-split recomputation of the softmax, and the first key tile is already in
 //      flight while the prologue runs.  The new token's K and V are taken from LDS, never from the page being written.
 //      Same operation order as the split kernels (scores: one fma chain over d; l: page sums in key order, pages in order;
-//      PV: page chains, 4 pages per super-block in order, super-blocks in order).  grid = (R, nkv), block 256.
+//      PV: page chains, 4 pages per super-block in order, super-blocks in order).  grid = (nkv, R), block 256.
 struct DecAttnArgs {
   const float* part; int slices; size_t slice_stride; int ncols;
   const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
@@ -1051,7 +1051,7 @@ template <int HD, int GQ, bool NEWTOK>
 __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const AttnGeom& g = a.g;
-  const int r = blockIdx.x, kvh = blockIdx.y;
+  const int kvh = blockIdx.x, r = blockIdx.y;   // heads fastest: the 16 blocks of a row read 16 adjacent 8 KiB pieces of each page
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int n_out = g.nq * HD;
   if (!a.row_active[r]) {
