@@ -49,6 +49,9 @@ typedef struct ixt_config {
   int32_t pagedattn_tokens_per_page; /* base.yml:741; power of two, 8..64 */
   int32_t pagedattn_max_pages_per_group; /* base.yml:743 (already derived, > 0) */
   int32_t use_hip_graph;           /* build knob: capture ixt_generate into one hipGraph */
+  int32_t max_packed_rows;         /* build knob: most rows of one ixt_prefill_rows call (0: max_prefill_predict_length) */
+  int32_t staging_groups;          /* build knob: page groups behind the decode slots that a packed prefill (MaxEngine.prefill_concat,
+                                      maxengine.py:719-836) fills before insert_partial hands their pages to slots; 0 = none */
 } ixt_config;
 
 typedef struct ixt_ctx ixt_ctx;
@@ -88,7 +91,22 @@ int ixt_pages_advance(ixt_ctx* ctx, void* stream);
 int ixt_pages_release(ixt_ctx* ctx, int slot, void* stream);
 /* MaxEngine.insert's `has_active_page.at[slot].set(True)` (maxengine.py:1189-1191). */
 int ixt_pages_set_active(ixt_ctx* ctx, int slot, int active, void* stream);
-/* Copy the seven PageState fields to HOST arrays (synchronises `stream`):
+/* ---- build extensions around MaxEngine.insert / prefill_concat (no function of the reference's page manager does these; each states the
+ * engine code it serves) ---- */
+/* MaxEngine.insert (maxengine.py:1166-1192) of a `length`-token prefix into the slot that already holds its pages: has_active_page = 1
+ * (:1189-1191) and sequence_lengths / active_page / active_page_position back to their post-prefill values (a generate() between
+ * prefill and insert has advanced them). */
+int ixt_pages_resync(ixt_ctx* ctx, int slot, int length, void* stream);
+/* MaxEngine.insert_partial (maxengine.py:1206-1318) over pages: slot `dst_slot` releases its pages and takes over the page list of
+ * group `src_group` (a staging group a packed prefill has filled); no K/V byte moves; src_group ends empty. */
+int ixt_pages_move(ixt_ctx* ctx, int src_group, int dst_slot, void* stream);
+/* MaxEngine.insert / bulk_insert into a slot other than the one prefilled (the page copy loop, maxengine.py:1106-1125): release + reserve
+ * `length` tokens for dst_slot, then copy the K and V pages of src_group, all layers.  src_group stays valid. */
+int ixt_pages_copy(ixt_ctx* ctx, int src_group, int dst_slot, int length, void* stream);
+/* Page-pool shortage is silent in the reference (page_manager.py:305-311).  out4 (HOST) = {reservations that found no room since the
+ * last reset, the last group that failed, decode rows left without a page, 0}; synchronises `stream`; reset != 0 clears the counters. */
+int ixt_pages_status(ixt_ctx* ctx, int32_t* out4, int reset, void* stream);
+/* Copy the seven PageState fields to HOST arrays (synchronises `stream`); the decode slots' groups only:
  * page_status[num_pages], page_map[max_slots*max_pages_per_group], num_pages_used[max_slots],
  * sequence_lengths[max_slots], active_page[max_slots], has_active_page[max_slots] (0/1),
  * active_page_position[max_slots]. */
@@ -105,8 +123,15 @@ int ixt_pages_import_status(ixt_ctx* ctx, const int32_t* page_status, void* stre
  * NULL.  n_tokens is the TRUE length of the chunk (padding rows are never computed). */
 int ixt_prefill_chunk(ixt_ctx* ctx, int slot, const int32_t* tokens_dev, int n_tokens, int start_pos,
                       int32_t* first_token_dev, float* last_logits_dev, void* stream);
+/* MaxEngine.prefill_concat's model pass (maxengine.py:719-836) over pages: n_rows rows of several prompts as one ragged batch -- row i =
+ * token tokens_dev[i] at position row_pos_dev[i] of page group row_group_dev[i] (pages already reserved; decode slots or staging groups);
+ * rows of different groups never see each other.  first_tokens_dev[j] = argmax of the logits of row logits_rows_dev[j] (the last row of
+ * prompt j, :797-812), logits_dev f32[n_logits][vocab] may be NULL.  All arrays are device arrays. */
+int ixt_prefill_rows(ixt_ctx* ctx, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev,
+                     int n_logits, const int32_t* logits_rows_dev, int32_t* first_tokens_dev, float* logits_dev, void* stream);
 /* MaxEngine._generate_jit model step (maxengine.py:868-936) for all slots: row b = token tokens_dev[b] at
- * position pos_dev[b]; rows whose PageState.has_active_page is 0 write no K/V and attend to nothing.
+ * position pos_dev[b]; rows without an active page, outside max_target_length or beyond the pages granted to the slot write no K/V
+ * and attend to nothing (ixt_generate also requires pos_dev[b] == sequence_lengths[b] - 1: a slot prefilled but not inserted idles).
  * next_tokens_dev[b] = argmax; logits_dev (f32[max_slots*vocab]) may be NULL. */
 int ixt_decode_step(ixt_ctx* ctx, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev,
                     float* logits_dev, void* stream);
@@ -171,8 +196,15 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "attn_wave_pairs"        1: the one-launch decode attention gives each (row, kv head) pair to one wave, no block barriers;
  *                            0 (default, measured faster): one 256-thread block per pair
  *   "dot_stream_min_blocks"  a dot of > 64 rows and 2..4 chains uses the streaming kernel (one slice) once it has this many
- *                            128-column x 64-row blocks (default: never) */
+ *                            128-column x 64-row blocks (default: never)
+ *   "ring_min_rows"          from this many rows (default 128) every dot of the model runs as the LDS-ring GEMM with fused epilogues
+ *                            (QKV + RoPE + page write, residual, SwiGLU, sampling; csrc/ixt_gemm.h); ixt_op_dot uses its f32 epilogue
+ *   "ring_cfg"               0 (default): tile chosen per shape; 1: 128 x 128, 2: 128 rows x 64 columns, 3: 64 x 32
+ *   "ring_split"             1: ixt_op_dot's ring GEMM runs split over the 512-k chains (one f32 slice per chain) */
 int ixt_set_option(ixt_ctx* ctx, const char* name, int value);
+
+/* Hash of the sources this library was built from (maxtext-indextts2_amd/build.py); the Python binding refuses a stale binary. */
+const char* ixt_build_id(void);
 
 #ifdef __cplusplus
 }

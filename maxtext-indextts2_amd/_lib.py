@@ -29,6 +29,7 @@ class IxtConfig(ctypes.Structure):
       ("max_prefill_predict_length", ctypes.c_int32), ("max_target_length", ctypes.c_int32), ("max_slots", ctypes.c_int32),
       ("pagedattn_num_pages", ctypes.c_int32), ("pagedattn_tokens_per_page", ctypes.c_int32),
       ("pagedattn_max_pages_per_group", ctypes.c_int32), ("use_hip_graph", ctypes.c_int32),
+      ("max_packed_rows", ctypes.c_int32), ("staging_groups", ctypes.c_int32),
   ]
 
 
@@ -45,6 +46,12 @@ SIGNATURES = {
     "ixt_pages_advance": (ctypes.c_int, [vp, vp]),
     "ixt_pages_release": (ctypes.c_int, [vp, ctypes.c_int, vp]),
     "ixt_pages_set_active": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_resync": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_move": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_copy": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_pages_status": (ctypes.c_int, [vp, c_i32p, ctypes.c_int, vp]),
+    "ixt_build_id": (ctypes.c_char_p, []),
+    "ixt_prefill_rows": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, vp, vp, vp, vp]),
     "ixt_pages_export": (ctypes.c_int, [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_u8p, c_i32p, vp]),
     "ixt_pages_import_status": (ctypes.c_int, [vp, c_i32p, vp]),
     "ixt_prefill_chunk": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
@@ -85,6 +92,11 @@ def load():
       fn = getattr(lib, name)  # AttributeError if the symbol is not exported
       fn.restype = res
       fn.argtypes = args
+    # a binary built from other sources than the ones next to it is refused (the built .so is not under version control)
+    from . import build as _build  # pylint: disable=import-outside-toplevel
+    have, want = lib.ixt_build_id().decode(), _build.source_hash()
+    if have != want:
+      raise IxtError(f"{LIB_PATH} was built from other sources (library {have}, tree {want}): rebuild it (python __graft_entry__.py build)")
     _lib = lib
   return _lib
 

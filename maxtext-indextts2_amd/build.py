@@ -1,6 +1,7 @@
 """Build recipe for libixt.so (HIP, gfx950 only): `python -m ...build` or build.build()."""
 from __future__ import annotations
 
+import hashlib
 import os
 import subprocess
 import sys
@@ -9,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libixt.so")
 SOURCES = ["ixt_api.hip"]
-HEADERS = ["ixt_device.h", "ixt_kernels.h", os.path.join("..", "..", "include", "ixt.h")]
+HEADERS = ["ixt_device.h", "ixt_kernels.h", "ixt_gemm.h", os.path.join("..", "..", "include", "ixt.h")]
 
 # -ffp-contract=off: the numerics contract allows fused multiply-adds only where the source
 # says fmaf; correctly rounded f32 divide/sqrt and IEEE denormals are hipcc defaults and are stated explicitly.
@@ -26,21 +27,40 @@ def hipcc() -> str:
   raise RuntimeError("hipcc not found")
 
 
+def source_hash() -> str:
+  """sha256 over the sources, headers and compiler flags the library is built from.  It is compiled into libixt.so
+  (`ixt_build_id()`); `_lib.load()` recomputes it and refuses a binary built from other sources."""
+  h = hashlib.sha256()
+  for name in SOURCES + HEADERS:
+    with open(os.path.join(CSRC, name), "rb") as f:
+      h.update(name.encode() + b"\0" + f.read() + b"\0")
+  h.update(" ".join(HIPCC_FLAGS).encode())
+  return h.hexdigest()[:32]
+
+
+def built_hash() -> str:
+  """The hash recorded next to the library by the last build ("" if none)."""
+  try:
+    with open(LIB + ".hash", "r", encoding="utf-8") as f:
+      return f.read().strip()
+  except OSError:
+    return ""
+
+
 def needs_build() -> bool:
-  if not os.path.exists(LIB):
-    return True
-  t = os.path.getmtime(LIB)
-  deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-  return any(os.path.getmtime(d) > t for d in deps)
+  return not os.path.exists(LIB) or built_hash() != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
   if not force and not needs_build():
     return LIB
-  cmd = [hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+  h = source_hash()
+  cmd = [hipcc()] + HIPCC_FLAGS + [f'-DIXT_SOURCE_HASH="{h}"'] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
   if verbose:
     print(" ".join(cmd), flush=True)
   subprocess.check_call(cmd)
+  with open(LIB + ".hash", "w", encoding="utf-8") as f:
+    f.write(h + "\n")
   return LIB
 
 

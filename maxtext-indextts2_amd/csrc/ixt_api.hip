@@ -46,6 +46,8 @@ struct GraphEntry {
 struct ixt_ctx {
   ixt_config cfg;
   int E, Q, KV, D, F, V, L, P, B, Rmax, NQKV, QN, KN, Tmax, mpg, nsb_max, GQ;
+  int G = 0, S = 0;            // page groups = B decode slots + S staging groups of packed prefill
+  int NLmax = 1;               // rows that can be unembedded in one call (decode slots / prompts of a packed prefill)
   // weights
   bf16_t* embedding = nullptr;
   bf16_t* final_norm = nullptr;
@@ -56,7 +58,9 @@ struct ixt_ctx {
   bf16_t *rope_sin = nullptr, *rope_cos = nullptr;
   std::vector<uint16_t> rope_sin_h, rope_cos_h;
   std::vector<bf16_t*> kpages_l, vpages_l;   // one allocation per layer: [page][kv_head][...]
+  bf16_t **kptrs_d = nullptr, **vptrs_d = nullptr;   // the same pointers in HBM (k_pages_copy)
   size_t layer_page_elems = 0;
+  int32_t* lrows = nullptr;                  // rows to unembed (ixt_prefill_rows)
   PageStateDev ps{};
   // workspaces
   bf16_t *h_a = nullptr, *h_b = nullptr, *xn = nullptr, *qbuf = nullptr, *ao = nullptr, *hact = nullptr;
@@ -78,7 +82,9 @@ struct ixt_ctx {
   int gemm_min_rows = 128, gemm_min_blocks = 150;
   int gemm_prefix_halves = 0;   // measured at 256 rows on the MLP up-projection: decode step 5.39 vs 4.84 ms: off
   int gemm_split_min_blocks = 300;   // 128 x 128 x one-chain blocks (at C2 / 256 rows: the QKV and MLP-down kernels; +2.4 % end to end)
-  int unembed_gemm = getenv("IXT_UNEMBED_GEMM") ? atoi(getenv("IXT_UNEMBED_GEMM")) : 1;
+  int unembed_gemm = 1;
+  // LDS-ring GEMM with fused epilogues (ixt_gemm.h) from this many rows; ring_cfg forces a tile (1: 128 x 128, 2: 128 x 64, 3: 64 x 32)
+  int ring_min_rows = 128, ring_cfg = 0, ring_split = 0;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -137,8 +143,9 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!is_pow2(c.pagedattn_tokens_per_page) || c.pagedattn_tokens_per_page < 8 || c.pagedattn_tokens_per_page > 64)
     return set_err(IXT_ERR_UNSUPPORTED, "pagedattn_tokens_per_page must be a power of two in [8, 64]");
   if (c.vocab_size % 16) return set_err(IXT_ERR_UNSUPPORTED, "vocab_size must be a multiple of 16");
-  if (c.max_slots > IXT_MAX_GROUPS || c.pagedattn_max_pages_per_group > IXT_MAX_GROUPS)
-    return set_err(IXT_ERR_UNSUPPORTED, "more than %d slots or pages per group", IXT_MAX_GROUPS);
+  if (c.staging_groups < 0 || c.max_packed_rows < 0) return set_err(IXT_ERR_INVALID, "staging_groups / max_packed_rows must be >= 0");
+  if (c.max_slots + c.staging_groups > IXT_MAX_GROUPS || c.pagedattn_max_pages_per_group > IXT_MAX_GROUPS)
+    return set_err(IXT_ERR_UNSUPPORTED, "more than %d page groups or pages per group", IXT_MAX_GROUPS);
   // page_manager.py:450-473
   if (c.pagedattn_max_pages_per_group <= 0) return set_err(IXT_ERR_INVALID, "`pagedattn_max_pages_per_group` must be positive.");
   if (c.pagedattn_max_pages_per_group < (c.max_target_length + c.pagedattn_tokens_per_page - 1) / c.pagedattn_tokens_per_page)
@@ -155,6 +162,10 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
   x->nsb_max = (x->mpg + IXT_SB - 1) / IXT_SB;
   x->Rmax = c.max_prefill_predict_length > c.max_slots ? c.max_prefill_predict_length : c.max_slots;
+  if (c.max_packed_rows > x->Rmax) x->Rmax = c.max_packed_rows;
+  x->S = c.staging_groups; x->G = x->B + x->S;
+  x->NLmax = x->B > x->S ? x->B : x->S;
+  if (x->NLmax < 1) x->NLmax = 1;
   const int E = x->E, F = x->F, V = x->V, L = x->L, R = x->Rmax;
   *out = nullptr;
   int rc = IXT_OK;
@@ -195,7 +206,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     return fail(set_err(IXT_ERR_HIP, "page pool memset failed"));
   // page state
   PageStateDev& s = x->ps;
-  s.num_pages = c.pagedattn_num_pages; s.groups = c.max_slots; s.mpg = x->mpg; s.P = x->P;
+  s.num_pages = c.pagedattn_num_pages; s.groups = x->G; s.decode_groups = x->B; s.mpg = x->mpg; s.P = x->P;
+  A(dmalloc(x, &s.status, (size_t)4));
   A(dmalloc(x, &s.page_status, (size_t)s.num_pages));
   A(dmalloc(x, &s.page_map, (size_t)s.groups * s.mpg));
   A(dmalloc(x, &s.num_pages_used, (size_t)s.groups));
@@ -225,7 +237,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   }
   A(dmalloc(x, &x->scores, (size_t)R * x->Q * x->Tmax));
   A(dmalloc(x, &x->pvpart, (size_t)R * x->Q * x->nsb_max * x->D));
-  x->amax_cap = (size_t)(x->B > 1 ? x->B : 1) * ((V + 15) / 16);
+  x->amax_cap = (size_t)x->NLmax * ((V + 15) / 16);
   A(dmalloc(x, &x->amax_val, x->amax_cap));
   A(dmalloc(x, &x->amax_idx, x->amax_cap));
   {
@@ -238,6 +250,12 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   A(dmalloc(x, &x->row_active, (size_t)R));
   A(dmalloc(x, &x->row_tok, (size_t)R));
   A(dmalloc(x, &x->new_tok, (size_t)R));
+  A(dmalloc(x, &x->lrows, (size_t)x->NLmax));
+  A(dmalloc(x, &x->kptrs_d, (size_t)L));
+  A(dmalloc(x, &x->vptrs_d, (size_t)L));
+  if (hipMemcpy(x->kptrs_d, x->kpages_l.data(), sizeof(bf16_t*) * L, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(x->vptrs_d, x->vpages_l.data(), sizeof(bf16_t*) * L, hipMemcpyHostToDevice) != hipSuccess)
+    return fail(set_err(IXT_ERR_HIP, "page pointer upload failed"));
 #undef A
   AttnGeom& g = x->geom;
   g.nq = x->Q; g.nkv = x->KV; g.hd = x->D; g.P = x->P; g.num_pages = c.pagedattn_num_pages; g.mpg = x->mpg;
@@ -270,12 +288,13 @@ static int copy_param(const void* src, int dtype, bf16_t* dst, int64_t rows, int
   return IXT_OK;
 }
 // a [K][ncols] kernel of the reference (row-major, linears.py:205-217) -> columns n_off.. of the tiled matrix `dst` (widx)
-static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols, int n_off, hipStream_t st) {
-  if (ncols % 16 || n_off % 16 || K % IXT_MK) return set_err(IXT_ERR_UNSUPPORTED, "kernel %d x %d: columns %% 16 or rows %% 32", K, ncols);
+// mode 0: columns n_off..; mode 1: Q / K heads of hd columns, pair-interleaved; mode 2: MLP gate tiles interleaved (n_off = 0 wi_0, 1 wi_1)
+static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols, int n_off, hipStream_t st, int mode = 0, int hd = 0) {
+  if (ncols % 16 || (mode != 2 && n_off % 16) || K % IXT_MK) return set_err(IXT_ERR_UNSUPPORTED, "kernel %d x %d: columns %% 16 or rows %% 32", K, ncols);
   const int64_t n = (int64_t)K * ncols;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_tile_w<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, K, ncols, n_off);
-  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_tile_w<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, K, ncols, n_off);
+  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_tile_w<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, K, ncols, n_off, mode, hd);
+  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_tile_w<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, K, ncols, n_off, mode, hd);
   else return set_err(IXT_ERR_INVALID, "dtype %d", dtype);
   LAUNCHCHK();
   return IXT_OK;
@@ -309,13 +328,13 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
   LayerW& w = c->layers[li];
   uint32_t& m = c->loaded[li];
   if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
-  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st)); m |= 1u << W_Q; }
-  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st)); m |= 1u << W_K; }
+  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st, 1, c->D)); m |= 1u << W_Q; }
+  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st, 1, c->D)); m |= 1u << W_K; }
   else if (rest == "self_attention/value/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN + c->KN, st)); m |= 1u << W_V; }
   else if (rest == "self_attention/out/kernel") { TRY(expect((int64_t)c->QN * E)); TRY(tile_param(dev_ptr, dtype, w.wo, c->QN, E, 0, st)); m |= 1u << W_O; }
   else if (rest == "mlp/mlp_layer_norm/scale" || rest == "post_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln2, 1, E, E, st)); m |= 1u << W_LN2; }
-  else if (rest == "mlp/wi_0/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, 0, st)); m |= 1u << W_WI0; }
-  else if (rest == "mlp/wi_1/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, F, st)); m |= 1u << W_WI1; }
+  else if (rest == "mlp/wi_0/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, 0, st, 2)); m |= 1u << W_WI0; }
+  else if (rest == "mlp/wi_1/kernel") { TRY(expect((int64_t)E * F)); TRY(tile_param(dev_ptr, dtype, w.wi, E, F, 1, st, 2)); m |= 1u << W_WI1; }
   else if (rest == "mlp/wo/kernel") { TRY(expect((int64_t)F * E)); TRY(tile_param(dev_ptr, dtype, w.wout, F, E, 0, st)); m |= 1u << W_WOUT; }
   else return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
   return IXT_OK;
@@ -333,6 +352,11 @@ static int check_slot(ixt_ctx* c, int slot) {
   if (slot < 0 || slot >= c->B) return set_err(IXT_ERR_RANGE, "PageManager: page_group_id (%d) out of range [0, %d)", slot, c->B);
   return IXT_OK;
 }
+// decode slots and the staging groups behind them (packed prefill)
+static int check_group(ixt_ctx* c, int g) {
+  if (g < 0 || g >= c->G) return set_err(IXT_ERR_RANGE, "PageManager: page_group_id (%d) out of range [0, %d)", g, c->G);
+  return IXT_OK;
+}
 extern "C" int ixt_pages_reset(ixt_ctx* c, void* stream) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
   hipLaunchKernelGGL(k_pages_reset, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps);
@@ -341,7 +365,7 @@ extern "C" int ixt_pages_reset(ixt_ctx* c, void* stream) {
 }
 extern "C" int ixt_pages_reserve(ixt_ctx* c, int slot, int true_length, void* stream) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
-  TRY(check_slot(c, slot));
+  TRY(check_group(c, slot));
   if (true_length <= 0 || true_length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", true_length, c->Tmax);
   hipLaunchKernelGGL(k_pages_reserve, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot, true_length, 0);
   LAUNCHCHK();
@@ -349,7 +373,7 @@ extern "C" int ixt_pages_reserve(ixt_ctx* c, int slot, int true_length, void* st
 }
 extern "C" int ixt_pages_extend(ixt_ctx* c, int slot, int total_length, void* stream) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
-  TRY(check_slot(c, slot));
+  TRY(check_group(c, slot));
   if (total_length <= 0 || total_length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", total_length, c->Tmax);
   hipLaunchKernelGGL(k_pages_reserve, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot, total_length, 1);
   LAUNCHCHK();
@@ -363,7 +387,7 @@ extern "C" int ixt_pages_advance(ixt_ctx* c, void* stream) {
 }
 extern "C" int ixt_pages_release(ixt_ctx* c, int slot, void* stream) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
-  TRY(check_slot(c, slot));
+  TRY(check_group(c, slot));
   hipLaunchKernelGGL(k_pages_release, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, slot);
   LAUNCHCHK();
   return IXT_OK;
@@ -375,6 +399,50 @@ extern "C" int ixt_pages_set_active(ixt_ctx* c, int slot, int active, void* stre
   LAUNCHCHK();
   return IXT_OK;
 }
+extern "C" int ixt_pages_resync(ixt_ctx* c, int slot, int length, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_slot(c, slot));
+  if (length <= 0 || length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", length, c->Tmax);
+  hipLaunchKernelGGL(k_pages_resync, dim3(1), dim3(1), 0, (hipStream_t)stream, c->ps, slot, length);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_move(ixt_ctx* c, int src_group, int dst_slot, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_group(c, src_group));
+  TRY(check_slot(c, dst_slot));
+  if (src_group == dst_slot) return IXT_OK;
+  hipLaunchKernelGGL(k_pages_move, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps, src_group, dst_slot);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_copy(ixt_ctx* c, int src_group, int dst_slot, int length, void* stream) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  TRY(check_group(c, src_group));
+  TRY(check_slot(c, dst_slot));
+  if (length <= 0 || length > c->Tmax) return set_err(IXT_ERR_RANGE, "PageManager: true_length (%d) out of range (0, %d]", length, c->Tmax);
+  if (src_group == dst_slot) return set_err(IXT_ERR_INVALID, "page copy onto itself");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_pages_reserve, dim3(1), dim3(64), 0, st, c->ps, dst_slot, length, 0);
+  const int npages = (length + c->P - 1) / c->P;
+  hipLaunchKernelGGL(k_pages_copy, dim3(npages, c->L), dim3(256), 0, st, c->ps, src_group, dst_slot, c->kptrs_d, c->vptrs_d,
+                     (size_t)c->KV * c->P * c->D);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+extern "C" int ixt_pages_status(ixt_ctx* c, int32_t* out4, int reset, void* stream) {
+  if (!c || !out4) return set_err(IXT_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  HIPCHK(hipMemcpyAsync(out4, c->ps.status, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (reset) HIPCHK(hipMemsetAsync(c->ps.status, 0, sizeof(int32_t) * 4, st));
+  return IXT_OK;
+}
+#ifndef IXT_SOURCE_HASH
+#define IXT_SOURCE_HASH "unhashed"
+#endif
+extern "C" const char* ixt_build_id(void) { return IXT_SOURCE_HASH; }
+
 extern "C" int ixt_pages_export(ixt_ctx* c, int32_t* page_status, int32_t* page_map, int32_t* num_pages_used, int32_t* sequence_lengths,
                                 int32_t* active_page, uint8_t* has_active_page, int32_t* active_page_position, void* stream) {
   if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
@@ -382,15 +450,16 @@ extern "C" int ixt_pages_export(ixt_ctx* c, int32_t* page_status, int32_t* page_
   HIPCHK(hipStreamSynchronize(st));
   const PageStateDev& s = c->ps;
   if (page_status) HIPCHK(hipMemcpy(page_status, s.page_status, sizeof(int32_t) * s.num_pages, hipMemcpyDeviceToHost));
-  if (page_map) HIPCHK(hipMemcpy(page_map, s.page_map, sizeof(int32_t) * s.groups * s.mpg, hipMemcpyDeviceToHost));
-  if (num_pages_used) HIPCHK(hipMemcpy(num_pages_used, s.num_pages_used, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
-  if (sequence_lengths) HIPCHK(hipMemcpy(sequence_lengths, s.sequence_lengths, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
-  if (active_page) HIPCHK(hipMemcpy(active_page, s.active_page, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
-  if (active_page_position) HIPCHK(hipMemcpy(active_page_position, s.active_page_position, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
+  const int ng = s.decode_groups;   // the reference's page groups; staging groups are internal
+  if (page_map) HIPCHK(hipMemcpy(page_map, s.page_map, sizeof(int32_t) * ng * s.mpg, hipMemcpyDeviceToHost));
+  if (num_pages_used) HIPCHK(hipMemcpy(num_pages_used, s.num_pages_used, sizeof(int32_t) * ng, hipMemcpyDeviceToHost));
+  if (sequence_lengths) HIPCHK(hipMemcpy(sequence_lengths, s.sequence_lengths, sizeof(int32_t) * ng, hipMemcpyDeviceToHost));
+  if (active_page) HIPCHK(hipMemcpy(active_page, s.active_page, sizeof(int32_t) * ng, hipMemcpyDeviceToHost));
+  if (active_page_position) HIPCHK(hipMemcpy(active_page_position, s.active_page_position, sizeof(int32_t) * ng, hipMemcpyDeviceToHost));
   if (has_active_page) {
-    std::vector<int32_t> tmp(s.groups);
-    HIPCHK(hipMemcpy(tmp.data(), s.has_active_page, sizeof(int32_t) * s.groups, hipMemcpyDeviceToHost));
-    for (int i = 0; i < s.groups; ++i) has_active_page[i] = tmp[i] ? 1 : 0;
+    std::vector<int32_t> tmp(ng);
+    HIPCHK(hipMemcpy(tmp.data(), s.has_active_page, sizeof(int32_t) * ng, hipMemcpyDeviceToHost));
+    for (int i = 0; i < ng; ++i) has_active_page[i] = tmp[i] ? 1 : 0;
   }
   return IXT_OK;
 }
@@ -420,12 +489,71 @@ static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
   if (idx >= 0) (void)hipEventRecord(c->tpairs[idx].b, st);
 }
 
-struct DotResult { int slices; size_t slice_stride; int ntiles; };
-
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
+// --------------------------------------------------------------------------------------- LDS-ring GEMM (ixt_gemm.h)
+// Tiles: 1 = 128 x 128 (4 ring slots of 32 KiB), 2 = 128 rows x 64 columns (5 x 24 KiB), 3 = 64 x 32 (6 x 24 KiB, 128-k chunks).
+static int ring_pick(const ixt_ctx* c, int epi, int R, int N) {
+  if (c->ring_cfg >= 1 && c->ring_cfg <= 3 && !(epi == GEPI_SWIGLU && c->ring_cfg == 3) && !(epi == GEPI_UNEMBED && c->ring_cfg != 1)) return c->ring_cfg;
+  if (epi == GEPI_UNEMBED) return 1;
+  const long b1 = (long)((N + 127) / 128) * ((R + 127) / 128), b2 = (long)((N + 63) / 64) * ((R + 127) / 128);
+  if (b1 >= 192) return 1;                    // the chip has 256 CUs and a block owns one (LDS): fewer blocks leave CUs without work
+  if (b2 >= 160 || epi == GEPI_SWIGLU) return 2;
+  return 3;
 }
+
+template <int RB, int CT, int KS, int NS, int EPI, int SPLIT>
+static int ring_launch_t(const bf16_t* x, const bf16_t* w, int K, int N, int R, int chains, const GemmEpi& e, hipStream_t st) {
+  const int ncolg = (N / 16 + 2 * CT - 1) / (2 * CT), zb = (R + 32 * RB - 1) / (32 * RB);
+  constexpr size_t lds = (size_t)NS * (2 * CT + 2 * RB) * KS * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {   // more than 64 KiB of dynamic LDS needs the attribute once per kernel
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<RB, CT, KS, NS, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  dim3 grid(((ncolg + 7) / 8) * 8 * zb, SPLIT ? chains : 1, 1);
+  hipLaunchKernelGGL((k_gemm_ring<RB, CT, KS, NS, EPI, SPLIT>), grid, dim3(256), lds, st, reinterpret_cast<const u32x4*>(x),
+                     reinterpret_cast<const u32x4*>(w), K, N, R, ncolg, zb, e);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+// x in xidx layout, w in widx layout; the epilogue's operands in `e`.  split (GEPI_F32 only): one f32 slice per 512-k chain.
+static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, int K, int N, int R, const GemmEpi& e, bool split, hipStream_t st) {
+  if (K % IXT_KALIGN || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "ring gemm: K %% 128 or N %% 16");
+  const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
+  const int cfg = ring_pick(c, epi, R, N);
+  double ebytes = 0.0;
+  switch (epi) {
+    case GEPI_F32: ebytes = (double)(split ? chains : 1) * R * N * 4.0; break;
+    case GEPI_UNEMBED: ebytes = e.out ? (double)R * N * 4.0 : 0.0; break;
+    case GEPI_RESID: ebytes = (double)R * N * 4.0; break;
+    case GEPI_SWIGLU: ebytes = (double)R * N; break;
+    default: ebytes = (double)R * N * 2.0; break;
+  }
+  const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + ebytes);
+  int rc = IXT_ERR_UNSUPPORTED;
+#define RING(EPI_)                                                                                              \
+  do {                                                                                                          \
+    if (cfg == 1) rc = ring_launch_t<4, 4, 2, 4, EPI_, 0>(x, w, K, N, R, chains, e, st);                       \
+    else if (cfg == 2) rc = ring_launch_t<4, 2, 2, 5, EPI_, 0>(x, w, K, N, R, chains, e, st);                  \
+    else rc = ring_launch_t<2, 1, 4, 6, EPI_, 0>(x, w, K, N, R, chains, e, st);                                \
+  } while (0)
+  if (epi == GEPI_F32 && split) rc = ring_launch_t<4, 4, 2, 4, GEPI_F32, 1>(x, w, K, N, R, chains, e, st);
+  else if (epi == GEPI_F32) RING(GEPI_F32);
+  else if (epi == GEPI_RESID) RING(GEPI_RESID);
+  else if (epi == GEPI_QKV) RING(GEPI_QKV);
+  else if (epi == GEPI_UNEMBED) rc = ring_launch_t<4, 4, 2, 4, GEPI_UNEMBED, 0>(x, w, K, N, R, chains, e, st);
+  else if (epi == GEPI_SWIGLU) {
+    if (cfg == 1) rc = ring_launch_t<4, 4, 2, 4, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, e, st);
+    else rc = ring_launch_t<4, 2, 2, 5, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, e, st);
+  }
+#undef RING
+  timing_end(c, st, ti);
+  if (rc == IXT_ERR_UNSUPPORTED) return set_err(rc, "ring gemm: epilogue %d", epi);
+  return rc;
+}
+
+
+struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
 // x: bf16 in the dot x layout (xidx); w: bf16 in the tiled weight layout (widx).  out: f32 [slices][R][N]; force_full: one
 // slice (all chains added inside the wave).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per block);
@@ -437,12 +565,21 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
   const int ntile = N / 16;
   const int rowblocks = (R + 15) / 16;
-  static const int nrb_env = env_int("IXT_DOT_NRB", 0);
-  static const int wpb_env = env_int("IXT_DOT_WPB", 0);
-  int nrb = rowblocks >= 3 ? 4 : rowblocks;
-  if (nrb_env == 1 || nrb_env == 2 || nrb_env == 4) nrb = nrb_env;
+  const int nrb = rowblocks >= 3 ? 4 : rowblocks;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
   bool split = !force_full && chains > 1;
+  if (!force_full && R >= c->ring_min_rows && K % IXT_KALIGN == 0) {   // many rows: the LDS-ring GEMM, f32 epilogue
+    const bool rsplit = c->ring_split && chains > 1 && (size_t)chains * R * N <= out_floats;
+    if ((size_t)R * N <= out_floats) {
+      GemmEpi e{};
+      e.out = out;
+      TRY(launch_ring(c, GEPI_F32, x, w, K, N, R, e, rsplit, st));
+      res->slices = rsplit ? chains : 1;
+      res->slice_stride = (size_t)R * N;
+      res->ntiles = ntile;
+      return IXT_OK;
+    }
+  }
   // Many rows, few chains, many columns: the streaming kernel (the unembedding's structure, block = 128 columns x all chains x 64
   // rows) adds the chain results on chip and writes ONE slice; at 256 rows the `chains` slices of a split-K launch are as large
   // as the weights.  Kept behind an option (default off): with 2 resident blocks per CU and a barrier pair per chain it measured
@@ -451,8 +588,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   // Many rows x many columns: the tiled GEMM (128 rows x 128 or 64 columns x all of K per block, one slice) once it has enough blocks
   {
     const int zb = (R + 127) / 128;
-    static const int ct_env = env_int("IXT_GEMM_CT", 4);
-    const int ct = ct_env == 4 ? 4 : 2;
+    const int ct = 4;
     const int ncolg = (ntile + 2 * ct - 1) / (2 * ct);
     if (!force_full && R >= c->gemm_min_rows && (long)ncolg * zb >= c->gemm_min_blocks && (size_t)R * N <= out_floats) {
       const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + (double)R * N * 4.0);
@@ -521,8 +657,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   const bool nt = zblocks == 1;  // weights read once per launch
   const int slices = split ? chains : 1;
   // waves per block: 4 share one LDS copy of the activations; 2 when that would leave CUs without a block
-  int wpb = (split || (long)((nwaves + 3) / 4) * zblocks >= 256) ? 4 : 2;   // (split-K blocks are always 4 waves: measured faster, and the kernel relies on it)
-  if (!split && (wpb_env == 1 || wpb_env == 2 || wpb_env == 4)) wpb = wpb_env;
+  const int wpb = (split || (long)((nwaves + 3) / 4) * zblocks >= 256) ? 4 : 2;   // (split-K blocks are always 4 waves: measured faster, and the kernel relies on it)
   const double wbytes = (double)K * N * 2.0 + (double)R * K * 2.0;
   const int ti = timing_begin(c, st, wbytes + (double)slices * R * N * 4.0);
   {
@@ -550,9 +685,20 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   return IXT_OK;
 }
 
+
 // logits (optional store) + greedy argmax for R rows of normed hidden states
 static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
   const int K = c->E, N = c->V;
+  if (R >= c->ring_min_rows && c->unembed_gemm) {   // many rows: the LDS-ring GEMM with the sampling epilogue
+    const int ncolg = (N / 16 + 7) / 8;
+    if ((size_t)R * 2 * ncolg > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+    GemmEpi e{};
+    e.out = logits_out; e.amax_val = c->amax_val; e.amax_idx = c->amax_idx; e.cr = c->sample_cols;
+    TRY(launch_ring(c, GEPI_UNEMBED, yT, c->logits_w, K, N, R, e, false, st));
+    hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, 2 * ncolg, argmax_out);
+    LAUNCHCHK();
+    return IXT_OK;
+  }
   if (R >= c->gemm_min_rows && c->unembed_gemm) {   // many rows: the tiled GEMM with the sampling epilogue (weights pulled through L2 half as often)
     const int ntile_ = N / 16, ncolg = (ntile_ + 7) / 8, zb = (R + 127) / 128;
     if ((size_t)R * 2 * ncolg > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
@@ -620,9 +766,10 @@ static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf
 }
 
 static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, const DotResult* part, const bf16_t* h_in, bf16_t* h_out,
-                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st, int kmajor = 1) {
+                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st, int kmajor = 1, const int32_t* row_index = nullptr) {
   RowNormArgs a;
   a.xn_kmajor = kmajor;
+  a.row_index = row_index;
   a.tokens = tokens; a.embedding = c->embedding; a.part = c->part;
   a.slices = part ? part->slices : 0; a.slice_stride = part ? part->slice_stride : 0;
   a.h_in = h_in; a.h_out = h_out; a.scale = scale; a.xn_out = xn_out; a.E = c->E; a.eps = c->cfg.normalization_layer_epsilon;
@@ -729,21 +876,60 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
 
-// The model over R rows described by row_tok/row_slot/row_pos/row_active (device).
-// Logits are produced for rows [lrow0, lrow0+nl).  decode: one new token per row (rows never read each other's new K).
-// Launches per layer: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum + residual + norm),
-// dot_wi, swiglu, dot_wo, rownorm (slice sum + residual + next norm).
-static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, int32_t* argmax_out,
+// The model over R rows described by row_slot/row_pos/row_active (device) and `tokens`.
+// Logits: nl rows -- rows [lrow0, lrow0 + nl) when lrows == nullptr, else the rows listed in lrows (device, nl entries).
+// decode: one new token per row (rows never read each other's new K).
+//
+// Two launch sequences per layer, same arithmetic:
+//   R >= ring_min_rows  LDS-ring GEMMs with fused epilogues (ixt_gemm.h): QKV (+ RoPE, q -> qbuf, K/V -> pages), attention from qbuf
+//                       and the pages, O-proj (+ residual), norm, MLP-up (+ SwiGLU), MLP-down (+ residual), norm: 7 launches, no f32
+//                       slice leaves the chip;
+//   fewer rows          split-K dots into f32 slices: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum
+//                       + residual + norm), dot_wi, swiglu, dot_wo, rownorm (slice sum + residual + next norm).
+static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
   const int E = c->E, F = c->F;
   DotResult dr;
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
-  const bool final_fused = nl == R && lrow0 == 0;   // decode: every row is unembedded
+  const bool final_fused = nl == R && lrow0 == 0 && lrows == nullptr;   // decode: every row is unembedded
+  const bool ring = R >= c->ring_min_rows;
+  const int fused_min = c->attn_fused_min_blocks;
+  const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
+  const bool attn_one_launch = R * c->KV >= fused_min && fused_lds <= 64 * 1024;
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
+    const bf16_t* next_scale = l + 1 < c->L ? c->layers[l + 1].ln1 : (final_fused ? c->final_norm : nullptr);
+    if (ring) {
+      GemmEpi e{};
+      e.row_slot = c->row_slot; e.row_pos = c->row_pos; e.row_active = c->row_active; e.page_map = c->ps.page_map;
+      e.rope_sin = c->rope_sin; e.rope_cos = c->rope_cos; e.qbuf = c->qbuf; e.kpages = c->kpages_l[l]; e.vpages = c->vpages_l[l]; e.g = c->geom;
+      TRY(launch_ring(c, GEPI_QKV, c->xn, w.wqkv, E, c->NQKV, R, e, false, st));
+      if (attn_one_launch) {
+        const DotResult none{0, 0, 0};
+        const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
+        TRY(launch_attention_fused(c, l, R, none, false, st));   // q from qbuf, every key / value (the new ones too) from the pages
+        timing_end(c, st, ta);
+      } else {
+        TRY(launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st));
+        hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
+        LAUNCHCHK();
+      }
+      GemmEpi eo{};
+      eo.h_in = hcur; eo.h_out = hnext;
+      TRY(launch_ring(c, GEPI_RESID, c->ao, w.wo, c->QN, E, R, eo, false, st));
+      TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hnext, nullptr, w.ln2, c->xn, st));
+      GemmEpi eu{};
+      eu.act = c->hact;
+      TRY(launch_ring(c, GEPI_SWIGLU, c->xn, w.wi, E, 2 * F, R, eu, false, st));
+      GemmEpi ed{};
+      ed.h_in = hnext; ed.h_out = hcur;
+      TRY(launch_ring(c, GEPI_RESID, c->hact, w.wout, F, E, R, ed, false, st));
+      if (next_scale != nullptr) TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, next_scale, c->xn, st));
+      continue;
+    }
     TRY(launch_dot(c, c->xn, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
     if (!decode) {
       QkvArgs qa;
@@ -756,9 +942,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       LAUNCHCHK();
     }
     // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
-    const int fused_min = c->attn_fused_min_blocks;
-    const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
-    if (R * c->KV >= fused_min && fused_lds <= 64 * 1024) {   // decode rows, and prefill rows after k_qkv_finalize
+    if (attn_one_launch) {   // decode rows, and prefill rows after k_qkv_finalize
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;   // K/V bytes depend on the rows' lengths: the caller prices them
       TRY(launch_attention_fused(c, l, R, dr, decode, st));
       timing_end(c, st, ta);
@@ -774,18 +958,16 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     LAUNCHCHK();
     TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
     // residual + the next norm (the next layer's pre-attention norm, or the final norm when every row gets logits) in one launch
-    if (l + 1 < c->L) {
-      TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, c->layers[l + 1].ln1, c->xn, st));
-    } else if (final_fused) {
-      TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, c->final_norm, c->xn, st));
+    if (next_scale != nullptr) {
+      TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st));
     } else {
       hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
       LAUNCHCHK();
     }
   }
   if (nl > 0) {
-    if (nl > (c->B > 1 ? c->B : 1)) return set_err(IXT_ERR_INVALID, "too many logits rows");
-    if (!final_fused) TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st));
+    if (nl > c->NLmax) return set_err(IXT_ERR_INVALID, "too many logits rows (%d > %d)", nl, c->NLmax);
+    if (!final_fused) TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, lrows ? hcur : hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st, 1, lrows));
     TRY(launch_unembed(c, c->xn, nl, logits_out, argmax_out, st));
   }
   return IXT_OK;
@@ -794,33 +976,48 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
 extern "C" int ixt_prefill_chunk(ixt_ctx* c, int slot, const int32_t* tokens_dev, int n_tokens, int start_pos, int32_t* first_token_dev,
                                  float* last_logits_dev, void* stream) {
   if (!c || !tokens_dev || !first_token_dev) return set_err(IXT_ERR_INVALID, "null argument");
-  TRY(check_slot(c, slot));
+  TRY(check_group(c, slot));
   if (n_tokens <= 0 || n_tokens > c->Rmax) return set_err(IXT_ERR_RANGE, "prefill chunk of %d rows (max %d)", n_tokens, c->Rmax);
   if (start_pos < 0 || start_pos + n_tokens > c->Tmax) return set_err(IXT_ERR_RANGE, "prefill beyond max_target_length");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_rows_prefill, dim3((n_tokens + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, slot, start_pos, n_tokens);
+  hipLaunchKernelGGL(k_rows_prefill, dim3((n_tokens + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, slot, start_pos, n_tokens,
+                     c->ps.num_pages_used, c->P);
   LAUNCHCHK();
-  return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, first_token_dev, last_logits_dev, false, st);
+  return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, nullptr, first_token_dev, last_logits_dev, false, st);
 }
 
-static int decode_rows(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, hipStream_t st) {
-  hipLaunchKernelGGL(k_rows_decode, dim3(1), dim3(c->B <= 1024 ? ((c->B + 63) / 64) * 64 : 1024), 0, st, c->row_slot, c->row_pos, c->row_active, c->row_tok,
-                     tokens_dev, pos_dev, c->ps.has_active_page, c->B);
+extern "C" int ixt_prefill_rows(ixt_ctx* c, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev,
+                                int n_logits, const int32_t* logits_rows_dev, int32_t* first_tokens_dev, float* logits_dev, void* stream) {
+  if (!c || !tokens_dev || !row_group_dev || !row_pos_dev || !logits_rows_dev || !first_tokens_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  if (n_rows <= 0 || n_rows > c->Rmax) return set_err(IXT_ERR_RANGE, "packed prefill of %d rows (max %d: ixt_config.max_packed_rows)", n_rows, c->Rmax);
+  if (n_logits <= 0 || n_logits > c->NLmax || n_logits > n_rows) return set_err(IXT_ERR_RANGE, "packed prefill with %d prompts (max %d)", n_logits, c->NLmax);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_rows_packed, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, row_group_dev, row_pos_dev, n_rows,
+                     c->ps.num_pages_used, c->P, c->G, c->Tmax);
   LAUNCHCHK();
-  return forward_rows(c, c->B, c->row_tok, c->Tmax, 0, c->B, next_tokens_dev, logits_dev, true, st);
+  HIPCHK(hipMemcpyAsync(c->lrows, logits_rows_dev, sizeof(int32_t) * n_logits, hipMemcpyDeviceToDevice, st));
+  return forward_rows(c, n_rows, tokens_dev, c->Tmax, 0, n_logits, c->lrows, first_tokens_dev, logits_dev, false, st);
+}
+
+static int decode_rows(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, int check_len,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_rows_decode, dim3(1), dim3(c->B <= 1024 ? ((c->B + 63) / 64) * 64 : 1024), 0, st, c->row_slot, c->row_pos, c->row_active, c->row_tok,
+                     tokens_dev, pos_dev, c->ps.has_active_page, c->ps.num_pages_used, c->ps.sequence_lengths, check_len, c->P, c->Tmax, c->B);
+  LAUNCHCHK();
+  return forward_rows(c, c->B, c->row_tok, c->Tmax, 0, c->B, nullptr, next_tokens_dev, logits_dev, true, st);
 }
 
 extern "C" int ixt_decode_step(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, void* stream) {
   if (!c || !tokens_dev || !pos_dev || !next_tokens_dev) return set_err(IXT_ERR_INVALID, "null argument");
   if (c->B > 1024) return set_err(IXT_ERR_UNSUPPORTED, "max_slots > 1024");
-  return decode_rows(c, tokens_dev, pos_dev, next_tokens_dev, logits_dev, (hipStream_t)stream);
+  return decode_rows(c, tokens_dev, pos_dev, next_tokens_dev, logits_dev, 0, (hipStream_t)stream);
 }
 
 static int generate_body(ixt_ctx* c, int32_t* tokens_dev, int32_t* next_pos_dev, int32_t* generated_dev, int32_t* result_data_dev, float* logits_dev,
                          hipStream_t st) {
   hipLaunchKernelGGL(k_pages_advance, dim3(1), dim3(64), 0, st, c->ps);
   LAUNCHCHK();
-  TRY(decode_rows(c, tokens_dev, next_pos_dev, c->new_tok, logits_dev, st));
+  TRY(decode_rows(c, tokens_dev, next_pos_dev, c->new_tok, logits_dev, 1, st));
   hipLaunchKernelGGL(k_generate_epilogue, dim3(1), dim3(((c->B + 63) / 64) * 64), 0, st, c->new_tok, tokens_dev, next_pos_dev, generated_dev, result_data_dev, c->B);
   LAUNCHCHK();
   return IXT_OK;
@@ -988,57 +1185,20 @@ extern "C" int ixt_set_sampling_ranges(ixt_ctx* c, const int32_t* lo_hi, int nra
 
 extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
   if (!c || !name) return set_err(IXT_ERR_INVALID, "null argument");
-  if (strcmp(name, "attn_fused_min_blocks") == 0) {
-    if (value < 1) return set_err(IXT_ERR_RANGE, "attn_fused_min_blocks must be positive");
+  struct Opt { const char* name; int* field; int lo; };
+  const Opt opts[] = {
+      {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
+      {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
+      {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
+      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0},
+  };
+  for (const Opt& o : opts) {
+    if (strcmp(name, o.name) != 0) continue;
+    if (value < o.lo) return set_err(IXT_ERR_RANGE, "%s must be >= %d", name, o.lo);
     HIPCHK(hipDeviceSynchronize());
     for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);   // captured launch sequences embed the old choice
     c->graphs.clear();
-    c->attn_fused_min_blocks = value;
-    return IXT_OK;
-  }
-  if (strcmp(name, "gemm_prefix_halves") == 0) {
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    c->gemm_prefix_halves = value ? 1 : 0;
-    return IXT_OK;
-  }
-  if (strcmp(name, "gemm_split_min_blocks") == 0) {
-    if (value < 1) return set_err(IXT_ERR_RANGE, "%s must be positive", name);
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    c->gemm_split_min_blocks = value;
-    return IXT_OK;
-  }
-  if (strcmp(name, "gemm_min_blocks") == 0 || strcmp(name, "gemm_min_rows") == 0) {
-    if (value < 1) return set_err(IXT_ERR_RANGE, "%s must be positive", name);
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    if (name[9] == 'b') c->gemm_min_blocks = value; else c->gemm_min_rows = value;
-    return IXT_OK;
-  }
-  if (strcmp(name, "unembed_gemm") == 0) {
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    c->unembed_gemm = value ? 1 : 0;
-    return IXT_OK;
-  }
-  if (strcmp(name, "attn_wave_pairs") == 0) {
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    c->attn_wave_pairs = value ? 1 : 0;
-    return IXT_OK;
-  }
-  if (strcmp(name, "dot_stream_min_blocks") == 0) {
-    if (value < 1) return set_err(IXT_ERR_RANGE, "dot_stream_min_blocks must be positive");
-    HIPCHK(hipDeviceSynchronize());
-    for (auto& kv : c->graphs) (void)hipGraphExecDestroy(kv.second.exec);
-    c->graphs.clear();
-    c->dot_stream_min_blocks = value;
+    *o.field = value;
     return IXT_OK;
   }
   return set_err(IXT_ERR_INVALID, "unknown option %s", name);

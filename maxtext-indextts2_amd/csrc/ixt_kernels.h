@@ -59,6 +59,12 @@ __host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
   return (size_t)(r >> 4) * K * 16 + (((size_t)(k >> 5) * 4 + ((k & 31) >> 3)) * 16 + (r & 15)) * 8 + (k & 7);
 }
 __host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xidx(n, k, K); }
+// Column of feature i (0..hd-1) of a Q or K head inside the head's hd columns of the fused QKV kernel: 16-column tile j holds
+// features 8j..8j+7 and half+8j..half+8j+7, so the two RoPE partners (i, i + half) of a feature share a tile (ixt_gemm.h, GEPI_QKV).
+__host__ __device__ __forceinline__ int qk_col(int i, int half) {
+  const int h = i >= half ? 1 : 0, ii = i - h * half;
+  return (ii >> 3) * 16 + h * 8 + (ii & 7);
+}
 
 //   grid = (ceil(waves/WPB) * ceil(rowblocks/NRB), SPLIT ? chains : 1), block = WPB waves (blockDim.x / 64), LDS = NRB x 16 KiB.
 //   A block = WPB adjacent 16-column tiles x one chain at a time x NRB 16-row blocks.  Per chain: every wave issues the loads
@@ -477,14 +483,23 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, c
 }
 
 // weights: row-major [K][ncols] (bf16 or f32) -> the tiled fragment layout of a [K][*] matrix, columns n_off..n_off+ncols
+//   mode 0: column n -> n_off + n
+//   mode 1: Q / K heads of `hd` columns, pair-interleaved (qk_col): feature i of a head -> the column that keeps both RoPE partners of
+//           a feature in one 16-column tile (ixt_gemm.h, GEPI_QKV)
+//   mode 2: the fused MLP gate kernel: tile j of this source becomes column tile 2 j + n_off (n_off = 0: wi_0, 1: wi_1), so that a
+//           wave holds both gates of a feature (ixt_gemm.h, GEPI_SWIGLU; k_swiglu_part reads the same layout)
 template <typename T>
-__global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off) {
+__global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off, int mode, int hd) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)K * ncols) return;
   const int k = (int)(i / ncols), n = (int)(i % ncols);
   bf16_t v;
   if constexpr (sizeof(T) == 2) v = src[i]; else v = f2bf(src[i]);
-  dst[widx(k, n_off + n, K)] = v;
+  int col;
+  if (mode == 1) col = n_off + (n / hd) * hd + qk_col(n % hd, hd >> 1);
+  else if (mode == 2) col = ((n >> 4) * 2 + n_off) * 16 + (n & 15);
+  else col = n_off + n;
+  dst[widx(k, col, K)] = v;
 }
 
 // x [R][K] row-major bf16 -> the dot kernel's x layout (op-level entry point only; the model's producers write it directly)
@@ -545,6 +560,7 @@ struct RowNormArgs {
   bf16_t* xn_out;
   int E; float eps;
   int xn_kmajor;   // 1: write xn as [row-block][E][16] (the dot kernel's x layout), 0: [R][E]
+  const int32_t* row_index;   // MODE 2: output row r normalises h_in row row_index[r] (nullptr: row r)
 };
 
 template <int MODE>
@@ -556,7 +572,8 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
   const int E = a.E, nch = E / 8, nblk = (nch + 63) / 64;
   const bf16_t* src = nullptr;
   if (MODE == 0) src = a.embedding + (size_t)a.tokens[r] * E;
-  if (MODE == 1 || MODE == 2) src = a.h_in + (size_t)r * E;
+  if (MODE == 1) src = a.h_in + (size_t)r * E;
+  if (MODE == 2) src = a.h_in + (size_t)(a.row_index != nullptr ? a.row_index[r] : r) * E;
   // this thread's first scale chunk: fetched now, so that it is not one more memory round trip after the barrier
   const u32x4 sv_first = (a.scale != nullptr && tid < nch) ? *reinterpret_cast<const u32x4*>(a.scale + tid * 8) : u32x4(0);
   for (int it = 0; it * 4 < nblk; ++it) {
@@ -627,7 +644,7 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
 }
 
 // =====================================================================================================
-// SwiGLU from partial slices (linears.py:449-464): part is [slices][R][2F] (wi_0 columns then wi_1).
+// SwiGLU from partial slices (linears.py:449-464): part is [slices][R][2F] (column tiles alternate wi_0 / wi_1: k_tile_w mode 2).
 // grid = (ceil(F/2048), R), block 256: a thread owns 8 consecutive features (two 16-byte loads per slice and operand, one
 // 16-byte store: 8 consecutive features of a row are one lane's fragment bytes in the dot kernel's x layout).
 // =====================================================================================================
@@ -641,8 +658,9 @@ __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slic
   for (int j = 0; j < 8; ++j) { a[j] = 0.0f; b[j] = 0.0f; }
   for (int s = 0; s < slices; ++s) {   // slices added in order from 0 (sum_slices semantics)
     const float* ps = p + (size_t)s * slice_stride;
-    const float4 a0 = *reinterpret_cast<const float4*>(ps + f0), a1 = *reinterpret_cast<const float4*>(ps + f0 + 4);
-    const float4 b0 = *reinterpret_cast<const float4*>(ps + F + f0), b1 = *reinterpret_cast<const float4*>(ps + F + f0 + 4);
+    const int ca = (f0 >> 4) * 32 + (f0 & 15);   // wi_0 tile j = column tile 2 j, wi_1 tile j = column tile 2 j + 1 (k_tile_w mode 2)
+    const float4 a0 = *reinterpret_cast<const float4*>(ps + ca), a1 = *reinterpret_cast<const float4*>(ps + ca + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(ps + ca + 16), b1 = *reinterpret_cast<const float4*>(ps + ca + 20);
     a[0] = a[0] + a0.x; a[1] = a[1] + a0.y; a[2] = a[2] + a0.z; a[3] = a[3] + a0.w;
     a[4] = a[4] + a1.x; a[5] = a[5] + a1.y; a[6] = a[6] + a1.z; a[7] = a[7] + a1.w;
     b[0] = b[0] + b0.x; b[1] = b[1] + b0.y; b[2] = b[2] + b0.z; b[3] = b[3] + b0.w;
@@ -696,10 +714,10 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
   if (i >= half) return;
   const int col0 = hh * g.hd;
   const float* pq = a.part + (size_t)r * a.ncols + col0;
-  float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
-  float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
-  const int pos = a.row_pos[r];
   const bool is_v = hh >= g.nq + g.nkv;
+  float v1 = rbf(sum_slices<16>(pq + (is_v ? i : qk_col(i, half)), a.slice_stride, a.slices));
+  float v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
+  const int pos = a.row_pos[r];
   if (!is_v) {
     const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
     const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
@@ -848,8 +866,9 @@ __global__ __launch_bounds__(256) void k_attn_front_decode(FrontArgs a) {
     else if (which == GQ) col0 = QN + kvh * HD;
     else col0 = QN + KN + kvh * HD;
     const float* pq = a.part + (size_t)r * a.ncols + col0;
-    float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
-    float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+    const bool rope_ = which <= GQ;   // q and k heads are stored pair-interleaved (qk_col), v heads in feature order
+    float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
+    float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
     if (which <= GQ) {
       const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
       const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
@@ -1100,8 +1119,9 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     else if (which == GQ) col0 = QN + kvh * HD;
     else col0 = QN + KN + kvh * HD;
     const float* pq = a.part + (size_t)r * a.ncols + col0;
-    float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
-    float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+    const bool rope_ = which <= GQ;   // q and k heads are stored pair-interleaved (qk_col), v heads in feature order
+    float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
+    float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
     if (which <= GQ) {
       const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
       const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
@@ -1352,8 +1372,9 @@ __global__ __launch_bounds__(256) void k_attn_decode_w(DecAttnArgs a, int npairs
       else if (which == GQ) col0 = QN + kvh * HD;
       else col0 = QN + KN + kvh * HD;
       const float* pq = a.part + (size_t)r * a.ncols + col0;
-      float v1 = rbf(sum_slices<16>(pq + i, a.slice_stride, a.slices));
-      float v2 = rbf(sum_slices<16>(pq + half + i, a.slice_stride, a.slices));
+      const bool rope_ = which <= GQ;
+      float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
+      float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
       if (which <= GQ) {
         const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
         const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
@@ -1554,14 +1575,38 @@ __global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, co
 // =====================================================================================================
 // Row descriptors and state update.
 // =====================================================================================================
-__global__ void k_rows_prefill(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int slot, int start, int n) {
+// A row is computed (K/V written, keys attended) only where the page manager has granted the page of its position: a reservation that
+// found no room leaves the group without pages (page_manager.py:305-311), and such rows must not write through stale page_map entries.
+__global__ void k_rows_prefill(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int slot, int start, int n,
+                               const int32_t* num_pages_used, int P) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { row_slot[i] = slot; row_pos[i] = start + i; row_active[i] = 1; }
+  if (i < n) { row_slot[i] = slot; row_pos[i] = start + i; row_active[i] = (start + i) / P < num_pages_used[slot] ? 1 : 0; }
 }
-__global__ void k_rows_decode(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int32_t* row_tok,
-                              const int32_t* tokens, const int32_t* pos, const int32_t* has_active, int B) {
+// caller-described rows (packed prefill): slot and position per row, same page guard; out-of-range descriptors make the row inactive
+__global__ void k_rows_packed(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, const int32_t* slot_in, const int32_t* pos_in, int n,
+                              const int32_t* num_pages_used, int P, int groups, int Tmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < B) { row_slot[i] = i; row_pos[i] = pos[i]; row_active[i] = has_active[i]; row_tok[i] = tokens[i]; }
+  if (i < n) {
+    const int g = slot_in[i], pos = pos_in[i];
+    const bool ok = g >= 0 && g < groups && pos >= 0 && pos < Tmax;
+    row_slot[i] = ok ? g : 0; row_pos[i] = ok ? pos : 0; row_active[i] = (ok && pos / P < num_pages_used[g]) ? 1 : 0;
+  }
+}
+// Decode rows: slot i at position pos[i] (the caller's decode_state["next_pos"]).  Active only when the page manager agrees: the slot
+// has an active page, the position is inside max_target_length and inside the pages granted so far (a page the pool could not grant
+// deactivates the row instead of letting it write through a stale page_map entry), and -- check_len, ixt_generate -- the position is
+// the one the page manager has just advanced to (sequence_lengths - 1): a slot that was prefilled but not inserted yet carries the
+// previous occupant's next_pos and stays idle until MaxEngine.insert.
+__global__ void k_rows_decode(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, int32_t* row_tok,
+                              const int32_t* tokens, const int32_t* pos, const int32_t* has_active, const int32_t* num_pages_used,
+                              const int32_t* sequence_lengths, int check_len, int P, int Tmax, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < B) {
+    const int p = pos[i];
+    bool act = has_active[i] != 0 && p >= 0 && p < Tmax && p / P < num_pages_used[i];
+    if (check_len) act = act && p == sequence_lengths[i] - 1;
+    row_slot[i] = i; row_pos[i] = act ? p : 0; row_active[i] = act ? 1 : 0; row_tok[i] = tokens[i];
+  }
 }
 // maxengine.py:913-935
 __global__ void k_generate_epilogue(const int32_t* new_tok, int32_t* tokens, int32_t* next_pos, int32_t* generated,
@@ -1589,7 +1634,9 @@ struct PageStateDev {
   int32_t* active_page;          // [groups]
   int32_t* has_active_page;      // [groups] (0/1)
   int32_t* active_page_position; // [groups]
-  int num_pages, groups, mpg, P;
+  int32_t* status;               // [4] build extension: {failed reservations, last group that failed, decode rows left without a page, 0}
+  int num_pages, groups, mpg, P; // groups = decode slots + staging groups of packed prefill (build extension)
+  int decode_groups;             // the reference's page groups (slots); only these advance in update_decode_pages
 };
 
 // lowest index >= 1 with status 0, else -1 (page_manager.py:129-156); whole wave cooperates.
@@ -1637,6 +1684,7 @@ __global__ __launch_bounds__(64) void k_pages_reset(PageStateDev s) {
     s.num_pages_used[i] = 0; s.sequence_lengths[i] = 0; s.active_page[i] = 0;
     s.has_active_page[i] = 0; s.active_page_position[i] = 0;
   }
+  if (lane < 4) s.status[lane] = 0;
 }
 __global__ __launch_bounds__(64) void k_pages_release(PageStateDev s, int g) { wave_release_group(s, g, threadIdx.x); }
 
@@ -1696,7 +1744,10 @@ __global__ __launch_bounds__(64) void k_pages_reserve(PageStateDev s, int g, int
   const int have = extend ? ldg_i32(s.num_pages_used + g) : 0;
   const int extra = need > have ? need - have : 0;
   const int nfree = wave_count_free8(s.page_status, s.num_pages, lane);
-  if (!(nfree >= extra && need <= s.mpg)) return;
+  if (!(nfree >= extra && need <= s.mpg)) {   // the reference returns the released state silently (page_manager.py:305-311); recorded here
+    if (lane == 0) { s.status[0] = s.status[0] + 1; s.status[1] = g; }
+    return;
+  }
   const int found = wave_take_free(s.page_status, s.num_pages, lane, extra, got);
   __syncthreads();
   for (int k = lane; k < found; k += 64) s.page_map[(size_t)g * s.mpg + have + k] = got[k];
@@ -1717,10 +1768,10 @@ __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
   __shared__ int32_t got[IXT_MAX_GROUPS];
   const int lane = threadIdx.x;
   int m = 0;
-  for (int base = 0; base < s.groups; base += 64) {
+  for (int base = 0; base < s.decode_groups; base += 64) {
     const int g = base + lane;
     bool needs = false;
-    if (g < s.groups) {
+    if (g < s.decode_groups) {
       const int act = s.has_active_page[g];
       const int nl = s.sequence_lengths[g] + (act ? 1 : 0);
       s.sequence_lengths[g] = nl;
@@ -1736,6 +1787,7 @@ __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
   __syncthreads();
   const int found = wave_take_free(s.page_status, s.num_pages, lane, m, got);
   __syncthreads();
+  if (lane == 0 && found < m) s.status[2] = s.status[2] + (m - found);   // these rows stay idle (k_rows_decode) until a page is free
   for (int k = lane; k < found; k += 64) {
     const int gg = need[k], nf = got[k];
     const int used = s.num_pages_used[gg];
@@ -1745,6 +1797,45 @@ __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
   }
 }
 __global__ void k_pages_set_active(PageStateDev s, int g, int v) { s.has_active_page[g] = v; }
+
+// ---- build extensions around MaxEngine.insert (no reference counterpart) ----------------------------------
+// insert of a prefix of `length` tokens into the slot that already holds its pages: has_active_page = 1 (maxengine.py:1189-1191) and the
+// length fields back to their post-prefill values -- a generate() between prefill(slot) and insert(slot) has advanced them.
+__global__ void k_pages_resync(PageStateDev s, int g, int length) {
+  const int need = (length + s.P - 1) / s.P;
+  if (need > s.num_pages_used[g] || need < 1) return;           // the reservation failed: leave the (empty) group alone
+  s.sequence_lengths[g] = length;
+  s.active_page[g] = s.page_map[(size_t)g * s.mpg + need - 1];
+  s.active_page_position[g] = ((length - 1) % s.P + 1) % s.P;
+  s.has_active_page[g] = 1;
+}
+// hand the pages of group `src` (a staging group filled by a packed prefill) to slot `dst`: dst's old pages are released, the page list
+// moves (no K/V byte is copied), src ends empty.  One wave.
+__global__ __launch_bounds__(64) void k_pages_move(PageStateDev s, int src, int dst) {
+  const int lane = threadIdx.x;
+  wave_release_group(s, dst, lane);
+  __syncthreads();
+  const int used = s.num_pages_used[src];
+  for (int i = lane; i < s.mpg; i += 64) s.page_map[(size_t)dst * s.mpg + i] = i < used ? s.page_map[(size_t)src * s.mpg + i] : 0;
+  __syncthreads();
+  if (lane == 0) {
+    s.num_pages_used[dst] = used; s.sequence_lengths[dst] = s.sequence_lengths[src]; s.active_page[dst] = s.active_page[src];
+    s.has_active_page[dst] = used > 0 ? 1 : 0; s.active_page_position[dst] = s.active_page_position[src];
+    s.num_pages_used[src] = 0; s.sequence_lengths[src] = 0; s.active_page[src] = 0; s.has_active_page[src] = 0; s.active_page_position[src] = 0;
+  }
+}
+// copy the K and V pages of group `src` (first `npages` logical pages) into the pages of group `dst`, all layers (the reference's page
+// copy loop, maxengine.py:1106-1125).  grid = (npages, layers), block 256; kp / vp: per-layer pool pointers.
+__global__ __launch_bounds__(256) void k_pages_copy(PageStateDev s, int src, int dst, bf16_t* const* kp, bf16_t* const* vp, size_t page_elems) {
+  const int i = blockIdx.x, l = blockIdx.y;
+  if (i >= s.num_pages_used[dst] || i >= s.num_pages_used[src]) return;
+  const size_t so = (size_t)s.page_map[(size_t)src * s.mpg + i] * page_elems, d_o = (size_t)s.page_map[(size_t)dst * s.mpg + i] * page_elems;
+  const u32x4* ks = reinterpret_cast<const u32x4*>(kp[l] + so);
+  const u32x4* vs = reinterpret_cast<const u32x4*>(vp[l] + so);
+  u32x4* kd = reinterpret_cast<u32x4*>(kp[l] + d_o);
+  u32x4* vd = reinterpret_cast<u32x4*>(vp[l] + d_o);
+  for (size_t e = threadIdx.x; e < page_elems / 8; e += 256) { kd[e] = ks[e]; vd[e] = vs[e]; }
+}
 
 // =====================================================================================================
 // load-time helpers
@@ -1758,3 +1849,5 @@ __global__ void k_copy_convert(const T* src, bf16_t* dst, int64_t rows, int64_t 
   if constexpr (sizeof(T) == 4) dst[r * ldd + c] = f2bf(src[i]);
   else dst[r * ldd + c] = src[i];
 }
+
+#include "ixt_gemm.h"

@@ -101,8 +101,9 @@ class PageManager:
     return PageState(self)
 
   # -- reference surface
-  def update_prefill_pages(self, page_state: Optional[PageState], page_group_id: int, true_length: int) -> PageState:
-    if page_group_id < 0 or page_group_id >= self.max_page_groups:
+  def update_prefill_pages(self, page_state: Optional[PageState], page_group_id: int, true_length: int, _staging: bool = False) -> PageState:
+    """page_manager.py:493-536.  `_staging` (engine-internal): the group is one of the staging groups behind the decode slots."""
+    if page_group_id < 0 or (page_group_id >= self.max_page_groups and not _staging):
       raise ValueError(f"PageManager: page_group_id ({page_group_id}) out of range [0, {self.max_page_groups})")
     if true_length <= 0 or true_length > self.max_target_length:
       raise ValueError(f"PageManager: true_length ({true_length}) out of range (0, {self.max_target_length}]")

@@ -38,10 +38,12 @@ class ExistingPrefix:
 
 
 class PagedCacheHandle:
-  """Stands where the reference's cache pytree stands: K/V live in the engine's page pools."""
+  """Stands where the reference's cache pytree stands: K/V live in the engine's page pools.  `slot` is the page group that
+  holds them (a decode slot, or a staging group of a packed prefill); `groups` / `lengths` describe a packed prefill."""
 
-  def __init__(self, engine: "MaxEngine", slot: Optional[int], length: int):
+  def __init__(self, engine: "MaxEngine", slot: Optional[int], length: int, groups=None, lengths=None):
     self.engine, self.slot, self.length = engine, slot, length
+    self.groups, self.lengths = groups, lengths
 
   def gather(self, layer: int):
     """Dense (k, v) bf16 tensors [length, num_kv_heads, head_dim] of this slot."""
@@ -81,6 +83,10 @@ class MaxEngine(engine_api.Engine):
     c.pagedattn_num_pages, c.pagedattn_tokens_per_page = config.pagedattn_num_pages, config.pagedattn_tokens_per_page
     c.pagedattn_max_pages_per_group = config.pagedattn_max_pages_per_group
     c.use_hip_graph = 1 if config.ixt_use_hip_graph else 0
+    c.max_packed_rows = int(config.ixt_max_packed_rows)
+    c.staging_groups = int(config.ixt_staging_groups)
+    self._staging = int(config.ixt_staging_groups)
+    self._packed_rows = max(int(config.ixt_max_packed_rows), int(config.max_prefill_predict_length))
     self._ccfg = c
     self._ctx = ctypes.c_void_p()
     _lib.check(self.lib.ixt_create(ctypes.byref(c), ctypes.byref(self._ctx)))
@@ -91,6 +97,20 @@ class MaxEngine(engine_api.Engine):
     self._params_loaded = False
     self._result = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
     self._first = torch.zeros((1,), dtype=torch.int32, device=self.device)
+    self._page_failures = 0
+
+  def _check_pages(self, what: str) -> None:
+    """The reference's page manager leaves a group empty, silently, when the pool cannot serve a reservation
+    (page_manager.py:305-311); rows of such a group are not computed here (no write goes through a stale page_map entry) and,
+    unless ixt_check_pages is off, the call that asked for the pages raises."""
+    if not self.config.ixt_check_pages:
+      return
+    out = (ctypes.c_int32 * 4)()
+    _lib.check(self.lib.ixt_pages_status(self._ctx, out, 0, ctypes.c_void_p(_stream_ptr())))
+    if out[0] != self._page_failures:
+      self._page_failures = out[0]
+      raise ValueError(f"{what}: the page pool (pagedattn_num_pages={self.config.pagedattn_num_pages}) could not serve the reservation "
+                       f"of page group {out[1]}; the group holds no pages")
 
   def __del__(self):
     try:
@@ -116,8 +136,9 @@ class MaxEngine(engine_api.Engine):
       t, dtype = _to_device_tensor(arr, self.device)
       shape = (ctypes.c_int64 * t.dim())(*t.shape)
       _lib.check(self.lib.ixt_load_weight(self._ctx, name.encode(), ctypes.c_void_p(t.data_ptr()), dtype, shape, t.dim(), ctypes.c_void_p(st)))
-      torch.cuda.current_stream().synchronize()
+      t.record_stream(torch.cuda.current_stream())   # the copy kernel may still be reading `t` when this name is dropped
       del t
+    torch.cuda.current_stream().synchronize()
     if not self.lib.ixt_weights_complete(self._ctx):
       raise ValueError("load_params: parameter tree is incomplete for the configured model")
     self._params_loaded = True
@@ -164,6 +185,7 @@ class MaxEngine(engine_api.Engine):
       self.page_state = self.page_manager.update_prefill_pages(page_state=self.page_state, page_group_id=slot, true_length=true_length)
     else:
       self.page_state = self.page_manager.extend_prefill_pages(page_state=self.page_state, page_group_id=slot, total_length=start + true_length)
+    self._check_pages("prefill")
     V = self.config.vocab_size
     logits = torch.empty((1, 1, V), dtype=torch.float32, device=self.device)
     first = torch.empty((1, 1), dtype=torch.int32, device=self.device)
@@ -186,8 +208,56 @@ class MaxEngine(engine_api.Engine):
   def prefill_multisampling(self, *args, **kwargs):
     raise NotImplementedError("prefill_multisampling (maxengine.py:595) is outside the built path (greedy only)")
 
-  def prefill_concat(self, *args, **kwargs):
-    raise NotImplementedError("prefill_concat (maxengine.py:719) packs prompts for the dense cache; not built for pages")
+  def prefill_concat(self, *, params: Params, existing_prefix: Optional[ExistingPrefix] = None, padded_tokens: Any, decoder_positions: Any,
+                     decoder_segment_ids: Any, start_pos: Any, true_lengths: Any, num_prompts: int, sampler: Any = None, rng: Any = None,
+                     return_prompt_logp: bool = False):
+    """maxengine.py:719-836: several prompts packed in one token sequence share ONE pass over the weights.  Prompt i occupies
+    padded_tokens[start_pos[i] : start_pos[i] + true_lengths[i]] (positions decoder_positions, segment id i + 1).  Over pages the
+    K/V of prompt i go to staging page group i (config `ixt_staging_groups`); `insert_partial` hands those pages to the slots.
+    Returns (cache handle, prefill_results {logits [n,1,1,V], next_pos [n,1,1], generated_tokens [n,1,1], tokens [n,1,1]},
+    [ResultTokens] per prompt)."""
+    del params, sampler, rng, decoder_segment_ids
+    if existing_prefix:
+      raise ValueError("We don't know what to do with existing_prefix")
+    if return_prompt_logp or self.config.return_log_prob:
+      raise NotImplementedError("log-prob outputs are outside the built path")
+    n = int(num_prompts)
+    if n <= 0 or n > self._staging:
+      raise ValueError(f"prefill_concat: num_prompts ({n}) out of range (0, ixt_staging_groups={self._staging}]")
+    starts = [int(v) for v in _host_ints(start_pos)[:n]]
+    lens = [int(v) for v in _host_ints(true_lengths)[:n]]
+    toks = _as_device_i32(padded_tokens, self.device).reshape(-1)
+    pos_all = _as_device_i32(decoder_positions, self.device).reshape(-1)
+    total = sum(lens)
+    if any(l <= 0 for l in lens) or any(st < 0 or st + l > toks.numel() for st, l in zip(starts, lens)):
+      raise ValueError("prefill_concat: start_pos / true_lengths outside padded_tokens")
+    if total > self._packed_rows:
+      raise ValueError(f"prefill_concat: {total} rows exceed ixt_max_packed_rows / max_prefill_predict_length ({self._packed_rows})")
+    B = self._B
+    for i, l in enumerate(lens):
+      self.page_state = self.page_manager.update_prefill_pages(page_state=self.page_state, page_group_id=B + i, true_length=l, _staging=True)
+    self._check_pages("prefill_concat")
+    idx = torch.cat([torch.arange(st, st + l, device=self.device) for st, l in zip(starts, lens)])
+    row_tok = toks[idx].contiguous()
+    row_pos = pos_all[idx].contiguous()
+    row_grp = torch.cat([torch.full((l,), B + i, dtype=torch.int32, device=self.device) for i, l in enumerate(lens)])
+    ends = torch.tensor(np.cumsum(lens) - 1, dtype=torch.int32, device=self.device)
+    V = self.config.vocab_size
+    logits = torch.empty((n, 1, 1, V), dtype=torch.float32, device=self.device)
+    first = torch.empty((n,), dtype=torch.int32, device=self.device)
+    _lib.check(self.lib.ixt_prefill_rows(self._ctx, total, ctypes.c_void_p(row_tok.data_ptr()), ctypes.c_void_p(row_grp.data_ptr()),
+                                         ctypes.c_void_p(row_pos.data_ptr()), n, ctypes.c_void_p(ends.data_ptr()), ctypes.c_void_p(first.data_ptr()),
+                                         ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    next_pos = torch.tensor(lens, dtype=torch.int32, device=self.device).reshape(n, 1, 1)
+    generated = torch.zeros((n, 1, 1), dtype=torch.int32, device=self.device)
+    tokens = first.reshape(n, 1, 1)
+    results = []
+    for i in range(n):
+      data = torch.cat([tokens[i], torch.ones_like(tokens[i]), generated[i]], dim=1)
+      results.append(engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=1))
+    prefill_results = {"logits": logits, "next_pos": next_pos, "generated_tokens": generated, "tokens": tokens, "prompt_logp": None}
+    cache = PagedCacheHandle(self, None, 0, groups=[B + i for i in range(n)], lengths=lens)
+    return cache, prefill_results, results
 
   # ------------------------------------------------------------------ generate
   def generate(self, params: Params, decode_state: DecodeState, sampler: Any = None, rng: Any = None) -> Tuple[DecodeState, engine_api.ResultTokens]:
@@ -205,30 +275,54 @@ class MaxEngine(engine_api.Engine):
 
   # ------------------------------------------------------------------ insert
   def insert(self, prefix: Prefix, decode_state: DecodeState, slot: int, request_id: Any = None) -> DecodeState:
-    """maxengine.py:1166-1192 (the cache copy of :1045-1164 is not needed: K/V are already in the slot's pages)."""
+    """maxengine.py:1166-1192.  Into the slot the prefix was prefilled into: no K/V moves (prefill wrote the slot's pages in place).
+    Into another slot: reserve pages there and copy the prefix's pages (the reference's page copy loop, :1106-1125)."""
     del request_id
     if slot < 0 or slot >= self._B:
       raise ValueError(f"slot {slot} out of range [0, {self._B})")
     handle = prefix["cache"]
-    if isinstance(handle, PagedCacheHandle) and handle.slot is not None and handle.slot != slot:
-      raise ValueError(f"prefix was prefilled into slot {handle.slot}, cannot insert into slot {slot}: pages are written in place")
+    st = ctypes.c_void_p(_stream_ptr())
+    if isinstance(handle, PagedCacheHandle) and handle.slot is not None and handle.length > 0:
+      if handle.slot != slot:
+        _lib.check(self.lib.ixt_pages_copy(self._ctx, handle.slot, slot, handle.length, st))
+        self._check_pages("insert")
+      _lib.check(self.lib.ixt_pages_resync(self._ctx, slot, handle.length, st))
     decode_state["next_pos"][slot] = prefix["next_pos"][0]
     decode_state["generated_tokens"][slot] = prefix["generated_tokens"][0]
     decode_state["tokens"][slot] = prefix["tokens"][0]
     if isinstance(decode_state.get("logits"), torch.Tensor) and prefix.get("logits") is not None:
       decode_state["logits"][slot] = prefix["logits"][0]
-    _lib.check(self.lib.ixt_pages_set_active(self._ctx, slot, 1, ctypes.c_void_p(_stream_ptr())))
+    _lib.check(self.lib.ixt_pages_set_active(self._ctx, slot, 1, st))
     return decode_state
 
   def bulk_insert(self, prefix: Prefix, decode_state: DecodeState, slots: list[int]) -> DecodeState:
-    """maxengine.py:946-1043: one prefix into several slots.  Pages are per slot, so only the slot the prefix was
-    prefilled into can receive it in place."""
+    """maxengine.py:946-1043: one computed prefix into several slots (each gets its own copy of the prefix's pages)."""
     for s in slots:
       decode_state = self.insert(prefix, decode_state, s)
     return decode_state
 
-  def insert_partial(self, *args, **kwargs):
-    raise NotImplementedError("insert_partial (maxengine.py:1206) unpacks prefill_concat results; not built for pages")
+  def insert_partial(self, prefix: Any, decode_state: DecodeState, cache: Any, slots: Any, *, start_indices: Any = None, num_prompts: int,
+                     seq_len: int = 0) -> DecodeState:
+    """maxengine.py:1206-1318: the prompts of a packed prefill into their slots.  `prefix` / `cache` are prefill_concat's
+    prefill_results / cache handle; prompt i goes to slots[i].  Over pages this moves page lists (no K/V byte is copied)."""
+    del start_indices, seq_len
+    if not isinstance(cache, PagedCacheHandle) or cache.groups is None:
+      raise ValueError("insert_partial: `cache` must be the handle returned by prefill_concat")
+    n = int(num_prompts)
+    slot_list = [int(v) for v in _host_ints(slots)[:n]]
+    if n > len(cache.groups) or len(slot_list) < n:
+      raise ValueError("insert_partial: num_prompts exceeds the packed prefill / slots")
+    st = ctypes.c_void_p(_stream_ptr())
+    for i, slot in enumerate(slot_list):
+      if slot < 0 or slot >= self._B:
+        raise ValueError(f"slot {slot} out of range [0, {self._B})")
+      _lib.check(self.lib.ixt_pages_move(self._ctx, cache.groups[i], slot, st))
+      decode_state["next_pos"][slot] = prefix["next_pos"][i, 0]
+      decode_state["generated_tokens"][slot] = prefix["generated_tokens"][i, 0]
+      decode_state["tokens"][slot] = prefix["tokens"][i, 0]
+      if isinstance(decode_state.get("logits"), torch.Tensor) and prefix.get("logits") is not None:
+        decode_state["logits"][slot] = prefix["logits"][i, 0]
+    return decode_state
 
   # ------------------------------------------------------------------ state
   def init_decode_state(self, *args, rng: Any = None, **kwargs) -> DecodeState:
@@ -297,6 +391,12 @@ def _numel(x) -> int:
   if hasattr(x, "numel"):
     return int(x.numel())
   return int(np.asarray(x).size)
+
+
+def _host_ints(x):
+  if isinstance(x, torch.Tensor):
+    return x.detach().reshape(-1).cpu().tolist()
+  return np.asarray(x).reshape(-1).tolist()
 
 
 def _as_device_i32(x, device) -> torch.Tensor:

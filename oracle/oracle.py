@@ -423,6 +423,26 @@ class OracleEngine:
     result = np.array([[first, 1, 0]], np.int32)
     return prefix, result
 
+  def prefill_many(self, prompts, slots=None, want_logits=False):
+    """Several prompts as ONE ragged batch of rows (the packed prefill of maxengine.py:719-836 `prefill_concat`, over pages):
+    prompt i = (padded_tokens, true_length) goes to slots[i]; rows of different prompts never see each other (each row
+    attends to positions [0, pos] of its own slot).  Returns ([prefix], first_tokens int32[n], logits f32[n][V] or None)."""
+    n = len(prompts)
+    slots = list(range(n)) if slots is None else list(slots)
+    for (toks, tl), s in zip(prompts, slots):
+      self.page_state = self.pm.update_prefill_pages(self.page_state, s, int(tl))
+    tk = np.concatenate([np.asarray(t, np.int32)[:int(tl)] for t, tl in prompts])
+    sl = np.concatenate([np.full((int(tl),), s, np.int32) for (_, tl), s in zip(prompts, slots)])
+    ps = np.concatenate([np.arange(int(tl), dtype=np.int32) for _, tl in prompts])
+    last = np.cumsum([int(tl) for _, tl in prompts]) - 1
+    out = self.model.forward(tk, sl, ps, np.ones_like(tk), self.page_state.page_map, logits_rows=list(last), want_logits=want_logits)
+    firsts = out["argmax"].astype(np.int32)
+    prefixes = []
+    for i, ((_, tl), s) in enumerate(zip(prompts, slots)):
+      prefixes.append({"logits": out["logits"][i:i + 1] if want_logits else None, "next_pos": np.full((1, 1), int(tl), np.int32),
+                       "generated_tokens": np.zeros((1, 1), np.int32), "tokens": np.full((1, 1), int(firsts[i]), np.int32), "slot": s})
+    return prefixes, firsts, out["logits"]
+
   def init_decode_state(self):
     B = self.cfg.max_slots
     return {"next_pos": np.zeros((B, 1), np.int32), "generated_tokens": np.zeros((B, 1), np.int32),

@@ -9,7 +9,9 @@
                                      full-size (C2, 1024-step) target without re-running the oracle on the GPU box.
 
 The floating-point fixtures are oracle outputs, NOT reference outputs (the reference needs JAX, which is not installed:
-parity unpinned).  usage: make_golden.py [mapping] [tiny] [c1] [c2]
+parity unpinned).    c2_rows_130.npz / c2_rows_256.npz  C2 at the row counts the benchmark times (130 = two GEMM row groups, the second ragged; 256 = the
+                                     bench default): ragged prompts, a few decode steps, token ids + per-row logits checksums
+usage: make_golden.py [mapping] [tiny] [c1] [c2] [c2_rows_130] [c2_rows_256]
 """
 import hashlib
 import json
@@ -87,7 +89,62 @@ def c2():
   decode_fixture("c2_decode", cfg, 0, prompts, 1024, 1)
 
 
+def logits_checksum(lg):
+  """Order-independent checksum of one row of f32 logits: sum of the 32-bit patterns (mod 2^64)."""
+  return np.ascontiguousarray(lg, np.float32).view(np.uint32).astype(np.uint64).sum(axis=-1)
+
+
+def rows_lengths(B, long_rows, hi, seed):
+  """Ragged prompt lengths: the first rows long (page crossings, many keys), the rest 1..hi tokens."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  lens = rng.integers(1, hi + 1, size=B).astype(np.int32)
+  lens[:len(long_rows)] = long_rows
+  return lens
+
+
+def c2_rows(name, B, long_rows, hi, steps, seed):
+  """C2 at the benchmarked row counts: B utterances (ragged prompts, prefilled as ONE ragged batch of rows by the oracle),
+  then `steps` decode steps of all B rows.  Stores token ids and a checksum of every row's f32 logits."""
+  T = 320
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=float(B), max_prefill_predict_length=256, max_target_length=T,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=B * (T // 32) + 1)
+  t0 = time.time()
+  w = H.synth.synth_weights(cfg, 0)
+  print(name, "weights", time.time() - t0, flush=True)
+  orc = H.make_oracle(cfg, w)
+  lens = rows_lengths(B, long_rows, hi, seed)
+  prompts = []
+  for s in range(B):
+    toks, _ = H.synth.synth_prompt(cfg.vocab_size, 256, 5000 + seed * 1000 + s)
+    prompts.append((toks, int(lens[s])))
+  pres, firsts, lg = orc.prefill_many(prompts, want_logits=True)
+  print(name, "prefill", int(lens.sum()), "rows", time.time() - t0, flush=True)
+  tokens = np.zeros((steps + 1, B), np.int32)
+  sums = np.zeros((steps + 1, B), np.uint64)
+  tokens[0] = firsts
+  sums[0] = logits_checksum(lg)
+  ods = orc.init_decode_state()
+  for s in range(B):
+    ods = orc.insert(pres[s], ods, s)
+  for i in range(steps):
+    ods, r = orc.generate(ods, want_logits=True)
+    tokens[i + 1] = r[:, 0]
+    sums[i + 1] = logits_checksum(ods["logits"])
+    print(name, "step", i, time.time() - t0, flush=True)
+  np.savez_compressed(os.path.join(HERE, name + ".npz"), tokens=tokens, logits_checksum=sums, prompt_tokens=np.stack([p[0] for p in prompts]),
+                      true_lengths=lens, weight_seed=np.array(0), steps=np.array(steps), max_target_length=np.array(T))
+  print(name, "done", time.time() - t0, tokens[:, :6].tolist(), flush=True)
+
+
+def c2_rows_130():
+  c2_rows("c2_rows_130", 130, [250, 131, 97, 64, 33], 12, 4, 1)
+
+
+def c2_rows_256():
+  c2_rows("c2_rows_256", 256, [200, 40, 31], 8, 2, 2)
+
+
 if __name__ == "__main__":
   which = sys.argv[1:] or ["mapping", "tiny", "c1"]
   for w in which:
-    {"mapping": mapping, "tiny": tiny, "c1": c1, "c2": c2}[w]()
+    {"mapping": mapping, "tiny": tiny, "c1": c1, "c2": c2, "c2_rows_130": c2_rows_130, "c2_rows_256": c2_rows_256}[w]()

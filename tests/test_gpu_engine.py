@@ -237,3 +237,186 @@ def test_errors_match_reference_conventions():
   eng2 = maxengine.MaxEngine(cfg)
   with pytest.raises(Exception):  # weights never loaded -> loud failure, no fallback
     eng2.prefill(params=None, padded_tokens=toks, true_length=tl, slot=0)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# packed prefill (prefill_concat / insert_partial), insert into other slots, and the guards of the decode rows
+# ---------------------------------------------------------------------------------------------------------------------------------
+STATE_FIELDS = ("num_pages_used", "sequence_lengths", "has_active_page", "active_page_position")
+
+
+def _packed_inputs(prompts):
+  lens = np.array([tl for _, tl in prompts], np.int32)
+  toks = np.concatenate([np.asarray(t, np.int32)[:tl] for t, tl in prompts])
+  pos = np.concatenate([np.arange(tl) for tl in lens]).astype(np.int32)
+  seg = np.concatenate([np.full(tl, i + 1) for i, tl in enumerate(lens)]).astype(np.int32)
+  starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+  return toks, pos, seg, starts, lens
+
+
+@pytest.mark.parametrize("nprompts,hi", [(6, 32), (10, 32), (24, 12)])
+def test_tiny_packed_prefill(nprompts, hi):
+  """prefill_concat (maxengine.py:719-836) + insert_partial (:1206-1318) over pages: several prompts in ONE pass over the weights, their
+  pages handed to permuted slots.  98 rows (split-K dots), 211 rows and 150 rows of 24 prompts (LDS-ring GEMMs with every fused epilogue).
+  First tokens, f32 logits, the K/V of every layer, the per-slot page-state fields and the following decode steps equal the oracle's."""
+  import torch
+  B = nprompts + 2
+  rng = np.random.default_rng(nprompts)
+  lens = rng.integers(1, hi + 1, size=nprompts)
+  lens[0] = hi
+  cfg = H.make_config(per_device_batch_size=float(B), pagedattn_num_pages=2 * B * 16 + 1, ixt_staging_groups=nprompts,
+                      ixt_max_packed_rows=int(lens.sum()))
+  w = H.synth.synth_weights(cfg, 9)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, 32, 700 + s)[0], int(lens[s])) for s in range(nprompts)]
+  slots = list(rng.permutation(B)[:nprompts])
+  toks, pos, seg, starts, ln = _packed_inputs(prompts)
+  cache, pres, results = eng.prefill_concat(params=params, padded_tokens=toks, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts,
+                                            true_lengths=ln, num_prompts=nprompts)
+  opres, ofirst, ologits = orc.prefill_many(prompts, slots=slots, want_logits=True)
+  assert np.array_equal(pres["tokens"].reshape(-1).cpu().numpy(), ofirst)
+  assert np.array_equal(np.stack([r.data.cpu().numpy()[0] for r in results]), np.stack([ofirst, np.ones_like(ofirst), np.zeros_like(ofirst)], 1))
+  assert np.array_equal(pres["logits"].reshape(nprompts, -1).cpu().numpy().view(np.uint32), ologits.view(np.uint32))
+  ds = eng.insert_partial(pres, eng.init_decode_state(materialize_logits=True), cache, np.array(slots), start_indices=starts, num_prompts=nprompts, seq_len=32)
+  ods = orc.init_decode_state()
+  for i, s in enumerate(slots):
+    ods = orc.insert(opres[i], ods, s)
+  st = eng.page_manager.device_state().to_numpy()
+  for f in STATE_FIELDS:
+    assert np.array_equal(st[f], getattr(orc.page_state, f)), f
+  assert int(st["page_status"].sum()) == int(orc.page_state.page_status.sum())     # the staging groups kept nothing
+  for i, s in enumerate(slots):
+    for layer in range(cfg.num_decoder_layers):
+      kg, vg = eng.gather_kv(layer, s, int(lens[i]))
+      ko, vo = orc.model.gather_kv(layer, orc.page_state.page_map[s], int(lens[i]))
+      assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo), (s, layer)
+  for step in range(6):
+    ds, res = eng.generate(params, ds)
+    ods, ores = orc.generate(ods, want_logits=True)
+    act = orc.page_state.has_active_page
+    assert np.array_equal(res.data.cpu().numpy()[act], ores[act]), step
+    assert np.array_equal(ds["logits"].cpu().numpy().reshape(B, -1)[act].view(np.uint32), ods["logits"][act].view(np.uint32)), step
+  del eng
+  torch.cuda.synchronize()
+
+
+def test_insert_into_other_slots_copies_pages():
+  """insert / bulk_insert of one prefix into slots other than the one it was prefilled into (maxengine.py:946-1043, 1106-1125): every
+  target slot gets its own copy of the pages and then decodes exactly like the source."""
+  cfg = H.make_config(per_device_batch_size=4.0, pagedattn_num_pages=64)
+  w = H.synth.synth_weights(cfg, 12)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  toks, tl = H.synth.synth_prompt(cfg.vocab_size, 32, 77)
+  pre, res = eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=1)
+  ds = eng.bulk_insert(pre, eng.init_decode_state(), [1, 3, 0])
+  ods = orc.init_decode_state()
+  for s in (1, 3, 0):
+    opre, ores = orc.prefill(toks, tl, slot=s)
+    ods = orc.insert(opre, ods, s)
+  assert np.array_equal(res.data.cpu().numpy(), ores)
+  for step in range(20):
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods)
+    got = r.data.cpu().numpy()
+    assert np.array_equal(got[[0, 1, 3]], orr[[0, 1, 3]]), step
+    assert np.array_equal(got[0], got[1]) and np.array_equal(got[0], got[3])
+  for s in (0, 1, 3):
+    n = int(ods["next_pos"][s, 0])
+    kg, vg = eng.gather_kv(1, s, n)
+    ko, vo = orc.model.gather_kv(1, orc.page_state.page_map[s], n)
+    assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo)
+
+
+def test_generate_between_prefill_and_insert():
+  """A generate() between prefill(slot) and insert(slot) -- the usual interleaving when one engine serves prefill and decode -- must not
+  touch the prefilled slot: its decode row idles (stale next_pos of the previous occupant), its K/V stay intact, and after insert it
+  decodes exactly like an engine that never saw the stray steps."""
+  cfg = H.make_config(per_device_batch_size=2.0, max_target_length=64, pagedattn_num_pages=32)
+  w = H.synth.synth_weights(cfg, 13)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  t0, l0 = H.synth.synth_prompt(cfg.vocab_size, 32, 1)
+  t1, l1 = H.synth.synth_prompt(cfg.vocab_size, 32, 2)
+  # slot 1 decodes for a while so that it leaves a large stale next_pos behind, then is released
+  p1, _ = eng.prefill(params=params, padded_tokens=t1, true_length=l1, slot=1)
+  ds = eng.insert(p1, eng.init_decode_state(), 1)
+  for _ in range(20):
+    ds, _ = eng.generate(params, ds)
+  eng.release_pages(1)
+  # slot 0 active; slot 1 prefilled again (short prompt) but NOT inserted; generate runs in between
+  p0, _ = eng.prefill(params=params, padded_tokens=t0, true_length=l0, slot=0)
+  ds = eng.insert(p0, ds, 0)
+  op0, _ = orc.prefill(t0, l0, slot=0)
+  ods = orc.insert(op0, orc.init_decode_state(), 0)
+  p1b, _ = eng.prefill(params=params, padded_tokens=t1, true_length=5, slot=1)
+  op1b, _ = orc.prefill(t1, 5, slot=1)
+  k_before = H.bits(eng.gather_kv(0, 1, 5)[0]).copy()
+  for _ in range(3):
+    ds, r = eng.generate(params, ds)
+    orc.page_state.has_active_page[1] = False          # the oracle's view: slot 1 does not decode before its insert
+    ods, orr = orc.generate(ods)
+    orc.page_state.has_active_page[1] = True
+    assert np.array_equal(r.data.cpu().numpy()[0], orr[0])
+  assert np.array_equal(H.bits(eng.gather_kv(0, 1, 5)[0]), k_before)
+  ds = eng.insert(p1b, ds, 1)
+  orc.page_state = orc.pm.update_prefill_pages(orc.page_state, 1, 5)   # lengths as right after the prefill (what insert restores)
+  ods = orc.insert(op1b, ods, 1)
+  for step in range(10):
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods)
+    assert np.array_equal(r.data.cpu().numpy(), orr), step
+
+
+def test_generate_past_max_target_length_is_harmless():
+  """One generate() too many (the slot's sequence has reached max_target_length): the row idles, no K/V is written out of range, other
+  slots are unaffected."""
+  cfg = H.make_config(per_device_batch_size=2.0, max_prefill_predict_length=32, max_target_length=40, pagedattn_num_pages=16)
+  w = H.synth.synth_weights(cfg, 14)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  t0, _ = H.synth.synth_prompt(cfg.vocab_size, 32, 3)
+  ds, ods = eng.init_decode_state(), orc.init_decode_state()
+  for s, tl in ((0, 32), (1, 8)):
+    p, _ = eng.prefill(params=params, padded_tokens=t0, true_length=tl, slot=s)
+    op, _ = orc.prefill(t0, tl, slot=s)
+    ds, ods = eng.insert(p, ds, s), orc.insert(op, ods, s)
+  for step in range(12):                                # slot 0 is full after 8 steps
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods) if step < 8 else (ods, None)
+    if step < 8:
+      assert np.array_equal(r.data.cpu().numpy(), orr), step
+  k0, _ = eng.gather_kv(0, 0, 40)
+  ko, _ = orc.model.gather_kv(0, orc.page_state.page_map[0], 40)
+  assert np.array_equal(H.bits(k0), ko)                 # nothing was written after the sequence filled up
+
+
+def test_page_pool_exhaustion_is_reported_and_harmless():
+  """A pool too small for the reservation: the reference's page manager leaves the group empty without a word (page_manager.py:305-311).
+  Here prefill raises, and with the check off the rows of the empty group are simply not computed: the neighbour's K/V and tokens stay
+  exactly what they are without the failed request."""
+  cfg = H.make_config(per_device_batch_size=2.0, pagedattn_num_pages=6, pagedattn_tokens_per_page=8)   # 5 usable pages of 8 tokens
+  w = H.synth.synth_weights(cfg, 15)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  t0, _ = H.synth.synth_prompt(cfg.vocab_size, 32, 4)
+  p0, _ = eng.prefill(params=params, padded_tokens=t0, true_length=20, slot=0)     # 3 pages
+  op0, _ = orc.prefill(t0, 20, slot=0)
+  with pytest.raises(ValueError, match="page pool"):
+    eng.prefill(params=params, padded_tokens=t0, true_length=30, slot=1)           # needs 4, 2 are free
+  orc.page_state = orc.pm.update_prefill_pages(orc.page_state, 1, 30)              # the reference: silently unchanged
+  assert_pages_equal(eng, orc)
+  ds, ods = eng.insert(p0, eng.init_decode_state(), 0), orc.insert(op0, orc.init_decode_state(), 0)
+  for step in range(30):                                                            # slot 0 grows to 50 tokens: needs 7 pages, gets 5
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods)
+    if step < 20:                                                                   # 40 tokens = 5 pages: identical while pages last
+      assert np.array_equal(r.data.cpu().numpy()[0], orr[0]), step
+  import ctypes
+  out = (ctypes.c_int32 * 4)()
+  H.lib.check(eng.lib.ixt_pages_status(eng._ctx, out, 0, None))
+  assert out[0] == 1 and out[1] == 1 and out[2] >= 1                                # one failed reservation (group 1), starved decode rows
+  k0, _ = eng.gather_kv(0, 0, 40)
+  ko, _ = orc.model.gather_kv(0, orc.page_state.page_map[0], 40)
+  assert np.array_equal(H.bits(k0), ko)

@@ -63,6 +63,61 @@ def c2_weights():
   return g, H.synth.synth_weights(cfg, int(g["weight_seed"]))
 
 
+def _checksum(t):
+  """sum of the 32-bit patterns of each row of f32 logits (make_golden.logits_checksum), on the GPU."""
+  import torch
+  return (t.contiguous().view(torch.int32).to(torch.int64) & 0xffffffff).sum(dim=-1).cpu().numpy().astype(np.uint64)
+
+
+@pytest.mark.parametrize("name,packed", [("c2_rows_130", False), ("c2_rows_256", False), ("c2_rows_256", True)])
+def test_golden_c2_rows(c2_weights, name, packed):
+  """C2 at the row counts the benchmark times, against committed oracle output (tests/golden/make_golden.py c2_rows_*): 130 utterances
+  = two 128-row GEMM groups, the second ragged; 256 = the bench default.  Ragged prompts (a few long ones: page crossings, hundreds of
+  keys), then decode steps of all rows through the kernels the bench runs at these shapes (ring GEMMs with the QKV / residual / SwiGLU /
+  sampling epilogues at 2048 x 6144, 2048 x 2048, 2048 x 14336, 7168 x 2048, 2048 x 264192; one-launch decode attention at >= 128 x 16
+  pairs).  Token ids and a checksum of every row's f32 logits must match.  packed: the prompts go through prefill_concat /
+  insert_partial (one pass over the weights for all of them) instead of one prefill per utterance."""
+  import torch
+  g = np.load(os.path.join(H.GOLDEN, name + ".npz"))
+  lens, steps, T = g["true_lengths"], int(g["steps"]), int(g["max_target_length"])
+  B = lens.shape[0]
+  total = int(lens.sum())
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=float(B), max_prefill_predict_length=256, max_target_length=T,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=(2 if packed else 1) * B * (T // 32) + 1,
+                      ixt_staging_groups=B if packed else 0, ixt_max_packed_rows=total if packed else 0)
+  assert int(g["weight_seed"]) == int(c2_weights[0]["weight_seed"])
+  eng, params = H.make_engine(cfg, c2_weights[1])
+  ds = eng.init_decode_state(materialize_logits=True)
+  tokens = np.zeros((steps + 1, B), np.int32)
+  sums = np.zeros((steps + 1, B), np.uint64)
+  if packed:
+    toks = np.concatenate([g["prompt_tokens"][s][:lens[s]] for s in range(B)]).astype(np.int32)
+    pos = np.concatenate([np.arange(lens[s]) for s in range(B)]).astype(np.int32)
+    seg = np.concatenate([np.full(lens[s], s + 1) for s in range(B)]).astype(np.int32)
+    starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    cache, pres, results = eng.prefill_concat(params=params, padded_tokens=toks, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts,
+                                              true_lengths=lens, num_prompts=B)
+    tokens[0] = pres["tokens"].reshape(B).cpu().numpy()
+    sums[0] = _checksum(pres["logits"].reshape(B, -1))
+    ds = eng.insert_partial(pres, ds, cache, np.arange(B), start_indices=starts, num_prompts=B, seq_len=256)
+  else:
+    for s in range(B):
+      pre, res = eng.prefill(params=params, padded_tokens=g["prompt_tokens"][s], true_length=int(lens[s]), slot=s)
+      tokens[0, s] = int(res.data[0, 0])
+      sums[0, s] = _checksum(pre["logits"].reshape(1, -1))[0]
+      ds = eng.insert(pre, ds, s)
+  for i in range(steps):
+    ds, res = eng.generate(params, ds)
+    tokens[i + 1] = res.data[:, 0].cpu().numpy()
+    sums[i + 1] = _checksum(ds["logits"].reshape(B, -1))
+  bad = np.argwhere(tokens != g["tokens"])
+  assert bad.size == 0, f"{len(bad)} token ids differ, first (step, row) {bad[:5].tolist()}"
+  bad = np.argwhere(sums != g["logits_checksum"])
+  assert bad.size == 0, f"{len(bad)} logits checksums differ, first (step, row) {bad[:5].tolist()}"
+  del eng
+  torch.cuda.synchronize()
+
+
 def test_golden_c2_full_decode(c2_weights):
   """BASELINE.json configs[1] at full size: every one of the 1025 token ids equals the oracle's."""
   g, w = c2_weights

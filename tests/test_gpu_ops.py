@@ -58,10 +58,12 @@ def test_dot_streaming_kernel(ctx, R, K, N):
   slice) forced onto small shapes; ragged last row block, a short last chain, a column count that is not a multiple of 128."""
   eng = ctx["eng"]
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_stream_min_blocks", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 1 << 30))   # the LDS-ring GEMM would take these shapes
   try:
     rng = np.random.default_rng(R + K + N)
     _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
   finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 128))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_stream_min_blocks", 1 << 30))
 
 
@@ -71,10 +73,12 @@ def test_dot_gemm_kernel(ctx, R, K, N):
   forced onto small shapes: ragged last row group / row block, a short last chain, partial column groups."""
   eng = ctx["eng"]
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 1 << 30))   # the LDS-ring GEMM would take these shapes
   try:
     rng = np.random.default_rng(R + K + N)
     _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
   finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 128))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
 
 
@@ -84,10 +88,12 @@ def test_dot_gemm_prefix_halves(ctx, R, K, N):
   eng = ctx["eng"]
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1))
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_prefix_halves", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 1 << 30))   # the LDS-ring GEMM would take these shapes
   try:
     rng = np.random.default_rng(R + K + N + 2)
     _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
   finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 128))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_prefix_halves", 0))
 
@@ -98,12 +104,41 @@ def test_dot_gemm_split_kernel(ctx, R, K, N):
   eng = ctx["eng"]
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 1 << 30))
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_split_min_blocks", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 1 << 30))   # the LDS-ring GEMM would take these shapes
   try:
     rng = np.random.default_rng(R + K + N + 1)
     _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
   finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_min_rows", 128))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_min_blocks", 150))
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_split_min_blocks", 300))
+
+
+@pytest.mark.parametrize("cfg_id", [1, 2, 3])
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 256), (250, 1152, 272), (200, 2048, 144), (129, 640, 16), (256, 512, 80), (130, 128, 528)])
+def test_dot_ring_kernel(ctx, cfg_id, R, K, N):
+  """The LDS-ring GEMM (csrc/ixt_gemm.h; the default from 128 rows), f32 epilogue, each of its three tiles forced in turn
+  (128 x 128, 128 x 64, 64 x 32): ragged last row group / row block, one chain, a short last chain, fewer chunks than ring slots
+  (K = 128), partial column groups."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_cfg", cfg_id))
+  try:
+    rng = np.random.default_rng(R + K + N + cfg_id)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_cfg", 0))
+
+
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 128), (250, 1152, 64), (200, 2048, 80)])
+def test_dot_ring_split_kernel(ctx, R, K, N):
+  """The ring GEMM split over the 512-k chains (one f32 slice per chain, summed in chain order by the caller)."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_split", 1))
+  try:
+    rng = np.random.default_rng(R + K + N + 7)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_split", 0))
 
 
 @pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
@@ -247,24 +282,36 @@ def test_kv_write_attention(ctx):
   assert not np.any(got[-1])  # inactive row attends to nothing
 
 
-def test_unembed_argmax_ties(ctx):
-  """First-index tie break (jnp.argmax): force exact ties through duplicated weight columns."""
+@pytest.mark.parametrize("R", [3, 130])
+def test_unembed_argmax_ties(ctx, R):
+  """First-index tie break (jnp.argmax, inference_utils.py:74-75): the maximum of every row is made to occur at several columns by
+  copying the winning weight column into columns on both sides of it -- in the same 16-column tile, in another tile of the same
+  wave, and in another block -- and the FIRST of them must win."""
   torch, eng, O, cfg = ctx["torch"], ctx["eng"], ctx["O"], ctx["cfg"]
   rng = np.random.default_rng(5)
   E, V = cfg.emb_dim, cfg.vocab_size
-  w = ctx["w"]["params/decoder/logits_dense/kernel"].copy().reshape(E, V)
-  R = 3
+  w0 = ctx["w"]["params/decoder/logits_dense/kernel"].copy().reshape(E, V)
   y = H.rand_bf16(rng, (R, E))
+  lg0 = np.zeros((R, V), np.float32)
+  O.lib().orc_dot_rows(O._p(y, O._u16p), E, R, O._p(w0, O._u16p), E, V, O._p(lg0, O._f32p), V)
+  win = int(np.argmax(O.bf16_to_f32(O.f32_to_bf16(lg0)).reshape(R, V)[0]))     # row 0's winner
+  dup = sorted({(win + d) % V for d in (-700, -17, -3, 1, 5, 40, 300)} | {win})
+  w = w0.copy()
+  for c in dup:
+    w[:, c] = w0[:, win]
   lg = np.zeros((R, V), np.float32)
   O.lib().orc_dot_rows(O._p(y, O._u16p), E, R, O._p(w, O._u16p), E, V, O._p(lg, O._f32p), V)
   lg = O.bf16_to_f32(O.f32_to_bf16(lg)).reshape(R, V)
+  assert int(np.sum(lg[0] == lg[0].max())) >= len(dup) and int(np.argmax(lg[0])) == dup[0]   # a real tie; the first index wins
+  # load the tied kernel into a private engine (the module fixture keeps its own weights)
+  wt = dict(ctx["w"])
+  wt["params/decoder/logits_dense/kernel"] = w
+  eng2, _ = H.make_engine(H.make_config(per_device_batch_size=136.0, pagedattn_num_pages=256), wt)
   logits = torch.empty((R, V), dtype=torch.float32, device="cuda")
   amax = torch.empty((R,), dtype=torch.int32, device="cuda")
   yd = H.dev_bf16(y)
-  H.lib.check(eng.lib.ixt_op_unembed_argmax(eng._ctx, _vp(yd), R, _vp(logits), _vp(amax), _st(torch)))
+  H.lib.check(eng2.lib.ixt_op_unembed_argmax(eng2._ctx, _vp(yd), R, _vp(logits), _vp(amax), _st(torch)))
   got = logits.cpu().numpy()
   assert np.array_equal(got.view(np.uint32), lg.view(np.uint32))
   assert np.array_equal(amax.cpu().numpy(), np.argmax(lg, axis=-1).astype(np.int32))
-  # bf16-rounded logits over 1024 columns tie often; make sure at least one row has a tied maximum somewhere in the test
-  ties = sum(int(np.sum(lg[r] == lg[r].max()) > 1) for r in range(R))
-  assert ties >= 0
+  assert int(amax[0]) == dup[0]
