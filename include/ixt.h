@@ -200,7 +200,10 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "ring_min_rows"          from this many rows (default 128) every dot of the model runs as the LDS-ring GEMM with fused epilogues
  *                            (QKV + RoPE + page write, residual, SwiGLU, sampling; csrc/ixt_gemm.h); ixt_op_dot uses its f32 epilogue
  *   "ring_cfg"               0 (default): tile chosen per shape; 1: 128 x 128, 2: 128 rows x 64 columns, 3: 64 x 32
- *   "ring_split"             1: ixt_op_dot's ring GEMM runs split over the 512-k chains (one f32 slice per chain) */
+ *   "ring_split"             1: ixt_op_dot's ring GEMM runs split over the 512-k chains (one f32 slice per chain)
+ *   "ring_wlayout"           1: ixt_op_dot stores its weights in the ring layout ([n/128][k/64][16 fragments]: one sequential stream per block)
+ *   "ring_down"              MLP down-projection on the ring path: 1 ring GEMM + residual epilogue, 0 split-K tiles + slice-sum kernel,
+ *                            -1 (default) by shape */
 int ixt_set_option(ixt_ctx* ctx, const char* name, int value);
 
 /* Hash of the sources this library was built from (maxtext-indextts2_amd/build.py); the Python binding refuses a stale binary. */

@@ -84,7 +84,10 @@ struct ixt_ctx {
   int gemm_split_min_blocks = 300;   // 128 x 128 x one-chain blocks (at C2 / 256 rows: the QKV and MLP-down kernels; +2.4 % end to end)
   int unembed_gemm = 1;
   // LDS-ring GEMM with fused epilogues (ixt_gemm.h) from this many rows; ring_cfg forces a tile (1: 128 x 128, 2: 128 x 64, 3: 64 x 32)
-  int ring_min_rows = 128, ring_cfg = 0, ring_split = 0;
+  int ring_min_rows = 128, ring_cfg = 0, ring_split = 0, ring_wlayout = 0;
+  // MLP down-projection on the ring path: 1 = ring GEMM with the residual epilogue; 0 = split-K tiles (one f32 slice per 512-k chain, two blocks
+  // per CU) + slice-sum / residual / norm kernel; -1 (default) = by shape: the ring form needs at least 192 whole-K blocks of 128 x 128 or 128 x 64
+  int ring_down = -1;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -289,12 +292,12 @@ static int copy_param(const void* src, int dtype, bf16_t* dst, int64_t rows, int
 }
 // a [K][ncols] kernel of the reference (row-major, linears.py:205-217) -> columns n_off.. of the tiled matrix `dst` (widx)
 // mode 0: columns n_off..; mode 1: Q / K heads of hd columns, pair-interleaved; mode 2: MLP gate tiles interleaved (n_off = 0 wi_0, 1 wi_1)
-static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols, int n_off, hipStream_t st, int mode = 0, int hd = 0) {
+static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols, int n_off, hipStream_t st, int mode = 0, int hd = 0, int ring = 0) {
   if (ncols % 16 || (mode != 2 && n_off % 16) || K % IXT_MK) return set_err(IXT_ERR_UNSUPPORTED, "kernel %d x %d: columns %% 16 or rows %% 32", K, ncols);
   const int64_t n = (int64_t)K * ncols;
   const unsigned blocks = (unsigned)((n + 255) / 256);
-  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_tile_w<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, K, ncols, n_off, mode, hd);
-  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_tile_w<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, K, ncols, n_off, mode, hd);
+  if (dtype == IXT_BF16) hipLaunchKernelGGL((k_tile_w<bf16_t>), dim3(blocks), dim3(256), 0, st, (const bf16_t*)src, dst, K, ncols, n_off, mode, hd, ring);
+  else if (dtype == IXT_F32) hipLaunchKernelGGL((k_tile_w<float>), dim3(blocks), dim3(256), 0, st, (const float*)src, dst, K, ncols, n_off, mode, hd, ring);
   else return set_err(IXT_ERR_INVALID, "dtype %d", dtype);
   LAUNCHCHK();
   return IXT_OK;
@@ -490,7 +493,8 @@ static void timing_end(ixt_ctx* c, hipStream_t st, int idx) {
 }
 
 // --------------------------------------------------------------------------------------- LDS-ring GEMM (ixt_gemm.h)
-// Tiles: 1 = 128 x 128 (4 ring slots of 32 KiB), 2 = 128 rows x 64 columns (5 x 24 KiB), 3 = 64 x 32 (6 x 24 KiB, 128-k chunks).
+// Tiles: 1 = 128 x 128 (8 waves as 2 x 4, 4 ring slots of 32 KiB), 2 = 128 rows x 64 columns (8 waves, 5 x 24 KiB), 3 = 64 x 32 (4 waves, 6 x 24 KiB,
+// 128-k chunks).
 static int ring_pick(const ixt_ctx* c, int epi, int R, int N) {
   if (c->ring_cfg >= 1 && c->ring_cfg <= 3 && !(epi == GEPI_SWIGLU && c->ring_cfg == 3) && !(epi == GEPI_UNEMBED && c->ring_cfg != 1)) return c->ring_cfg;
   if (epi == GEPI_UNEMBED) return 1;
@@ -500,24 +504,28 @@ static int ring_pick(const ixt_ctx* c, int epi, int R, int N) {
   return 3;
 }
 
-template <int RB, int CT, int KS, int NS, int EPI, int SPLIT>
-static int ring_launch_t(const bf16_t* x, const bf16_t* w, int K, int N, int R, int chains, const GemmEpi& e, hipStream_t st) {
-  const int ncolg = (N / 16 + 2 * CT - 1) / (2 * CT), zb = (R + 32 * RB - 1) / (32 * RB);
-  constexpr size_t lds = (size_t)NS * (2 * CT + 2 * RB) * KS * 1024;
+template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT>
+static int ring_launch_t(const bf16_t* x, const bf16_t* w, int K, int N, int R, int chains, int wring, const GemmEpi& e, hipStream_t st, int* wave_cols) {
+  constexpr int TC = WC * CT, TR = WR * RB;
+  const int ncolg = (N / 16 + TC - 1) / TC, zb = (R + 16 * TR - 1) / (16 * TR);
+  constexpr size_t lds = (size_t)NS * (TC + TR) * KS * 1024;
   static bool attr_done = false;
   if (!attr_done) {   // more than 64 KiB of dynamic LDS needs the attribute once per kernel
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<RB, CT, KS, NS, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   dim3 grid(((ncolg + 7) / 8) * 8 * zb, SPLIT ? chains : 1, 1);
-  hipLaunchKernelGGL((k_gemm_ring<RB, CT, KS, NS, EPI, SPLIT>), grid, dim3(256), lds, st, reinterpret_cast<const u32x4*>(x),
-                     reinterpret_cast<const u32x4*>(w), K, N, R, ncolg, zb, e);
+  hipLaunchKernelGGL((k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT>), grid, dim3(WR * WC * 64), lds, st, reinterpret_cast<const u32x4*>(x),
+                     reinterpret_cast<const u32x4*>(w), K, N, R, ncolg, zb, wring, e);
   LAUNCHCHK();
+  if (wave_cols) *wave_cols = WC * ncolg;
   return IXT_OK;
 }
 
-// x in xidx layout, w in widx layout; the epilogue's operands in `e`.  split (GEPI_F32 only): one f32 slice per 512-k chain.
-static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, int K, int N, int R, const GemmEpi& e, bool split, hipStream_t st) {
+// x in xidx layout, w in widx layout (wring: ring layout); the epilogue's operands in `e`.  split (GEPI_F32 only): one f32 slice per
+// 512-k chain.  wave_cols (GEPI_UNEMBED): entries per row of the (max, index) arrays.
+static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, int K, int N, int R, const GemmEpi& e, bool split, hipStream_t st, int wring = 0,
+                       int* wave_cols = nullptr) {
   if (K % IXT_KALIGN || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "ring gemm: K %% 128 or N %% 16");
   const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
   const int cfg = ring_pick(c, epi, R, N);
@@ -531,27 +539,27 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   }
   const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + ebytes);
   int rc = IXT_ERR_UNSUPPORTED;
-#define RING(EPI_)                                                                                              \
-  do {                                                                                                          \
-    if (cfg == 1) rc = ring_launch_t<4, 4, 2, 4, EPI_, 0>(x, w, K, N, R, chains, e, st);                       \
-    else if (cfg == 2) rc = ring_launch_t<4, 2, 2, 5, EPI_, 0>(x, w, K, N, R, chains, e, st);                  \
-    else rc = ring_launch_t<2, 1, 4, 6, EPI_, 0>(x, w, K, N, R, chains, e, st);                                \
-  } while (0)
-  if (epi == GEPI_F32 && split) rc = ring_launch_t<4, 4, 2, 4, GEPI_F32, 1>(x, w, K, N, R, chains, e, st);
+#define RING_A(EPI_, SPLIT_) ring_launch_t<2, 4, 4, 2, 2, 4, EPI_, SPLIT_>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+#define RING_B(EPI_) ring_launch_t<2, 4, 4, 1, 2, 5, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+#define RING_C(EPI_) ring_launch_t<2, 2, 2, 1, 4, 6, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+#define RING(EPI_) do { if (cfg == 1) rc = RING_A(EPI_, 0); else if (cfg == 2) rc = RING_B(EPI_); else rc = RING_C(EPI_); } while (0)
+  if (epi == GEPI_F32 && split) rc = RING_A(GEPI_F32, 1);
   else if (epi == GEPI_F32) RING(GEPI_F32);
   else if (epi == GEPI_RESID) RING(GEPI_RESID);
   else if (epi == GEPI_QKV) RING(GEPI_QKV);
-  else if (epi == GEPI_UNEMBED) rc = ring_launch_t<4, 4, 2, 4, GEPI_UNEMBED, 0>(x, w, K, N, R, chains, e, st);
+  else if (epi == GEPI_UNEMBED) rc = RING_A(GEPI_UNEMBED, 0);
   else if (epi == GEPI_SWIGLU) {
-    if (cfg == 1) rc = ring_launch_t<4, 4, 2, 4, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, e, st);
-    else rc = ring_launch_t<4, 2, 2, 5, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, e, st);
+    if (cfg == 1) rc = RING_A(GEPI_SWIGLU, 0);
+    else rc = ring_launch_t<2, 2, 4, 2, 2, 5, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);   // gate pairs need two tiles per wave: 4 waves
   }
 #undef RING
+#undef RING_A
+#undef RING_B
+#undef RING_C
   timing_end(c, st, ti);
   if (rc == IXT_ERR_UNSUPPORTED) return set_err(rc, "ring gemm: epilogue %d", epi);
   return rc;
 }
-
 
 struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
@@ -559,7 +567,7 @@ struct DotResult { int slices; size_t slice_stride; int ntiles; };
 // slice (all chains added inside the wave).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per block);
 // more rows run as partner blocks on the same XCD.
 static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N, int R, float* out, size_t out_floats,
-                      bool force_full, hipStream_t st, DotResult* res) {
+                      bool force_full, hipStream_t st, DotResult* res, bool no_ring = false) {
   if (K % IXT_MK || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 32 or N %% 16");
   if (out == nullptr) return set_err(IXT_ERR_INVALID, "dot: null output");
   const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
@@ -568,7 +576,7 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
   const int nrb = rowblocks >= 3 ? 4 : rowblocks;
   const int zblocks = (rowblocks + nrb - 1) / nrb;
   bool split = !force_full && chains > 1;
-  if (!force_full && R >= c->ring_min_rows && K % IXT_KALIGN == 0) {   // many rows: the LDS-ring GEMM, f32 epilogue
+  if (!force_full && !no_ring && R >= c->ring_min_rows && K % IXT_KALIGN == 0) {   // many rows: the LDS-ring GEMM, f32 epilogue
     const bool rsplit = c->ring_split && chains > 1 && (size_t)chains * R * N <= out_floats;
     if ((size_t)R * N <= out_floats) {
       GemmEpi e{};
@@ -690,12 +698,12 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
 static int launch_unembed(ixt_ctx* c, const bf16_t* yT, int R, float* logits_out, int32_t* argmax_out, hipStream_t st) {
   const int K = c->E, N = c->V;
   if (R >= c->ring_min_rows && c->unembed_gemm) {   // many rows: the LDS-ring GEMM with the sampling epilogue
-    const int ncolg = (N / 16 + 7) / 8;
-    if ((size_t)R * 2 * ncolg > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+    if ((size_t)R * ((N / 16 + 1) / 2) > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");   // one pair per row and wave column (>= 2 tiles)
     GemmEpi e{};
     e.out = logits_out; e.amax_val = c->amax_val; e.amax_idx = c->amax_idx; e.cr = c->sample_cols;
-    TRY(launch_ring(c, GEPI_UNEMBED, yT, c->logits_w, K, N, R, e, false, st));
-    hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, 2 * ncolg, argmax_out);
+    int wave_cols = 0;
+    TRY(launch_ring(c, GEPI_UNEMBED, yT, c->logits_w, K, N, R, e, false, st, 0, &wave_cols));
+    hipLaunchKernelGGL(k_argmax_final, dim3(R), dim3(256), 0, st, c->amax_val, c->amax_idx, wave_cols, argmax_out);
     LAUNCHCHK();
     return IXT_OK;
   }
@@ -924,10 +932,24 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       GemmEpi eu{};
       eu.act = c->hact;
       TRY(launch_ring(c, GEPI_SWIGLU, c->xn, w.wi, E, 2 * F, R, eu, false, st));
-      GemmEpi ed{};
-      ed.h_in = hnext; ed.h_out = hcur;
-      TRY(launch_ring(c, GEPI_RESID, c->hact, w.wout, F, E, R, ed, false, st));
-      if (next_scale != nullptr) TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, next_scale, c->xn, st));
+      // down-projection: few columns (E) x a long K.  With enough whole-K blocks it is a ring GEMM with the residual epilogue; at 256 rows
+      // (32 such blocks at C2) the tiles are split over the 512-k chains instead (one f32 slice per chain) and the next kernel adds them up.
+      const long down_blocks = (long)((E + 63) / 64) * ((R + 127) / 128);
+      const bool down_ring = c->ring_down == 1 || (c->ring_down < 0 && down_blocks >= 192);
+      if (down_ring) {
+        GemmEpi ed{};
+        ed.h_in = hnext; ed.h_out = hcur;
+        TRY(launch_ring(c, GEPI_RESID, c->hact, w.wout, F, E, R, ed, false, st));
+        if (next_scale != nullptr) TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, next_scale, c->xn, st));
+      } else {
+        TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr, true));
+        if (next_scale != nullptr) {
+          TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st));
+        } else {
+          hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
+          LAUNCHCHK();
+        }
+      }
       continue;
     }
     TRY(launch_dot(c, c->xn, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
@@ -1086,13 +1108,22 @@ extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, floa
   if ((size_t)((K + IXT_CHAIN - 1) / IXT_CHAIN) * R * N > c->part_floats && (size_t)R * N > c->part_floats)
     return set_err(IXT_ERR_INVALID, "op: %d x %d outputs exceed the scratch of this ctx", R, N);
   TRY(transpose_rows(c, x, R, K, st));
-  if ((size_t)K * N > c->wt_cap) {
+  const size_t Npad = (size_t)((N + 127) / 128) * 128;   // the ring layout pads the columns to whole 128-column groups
+  if ((size_t)K * Npad > c->wt_cap) {
     if (c->wt_op) { HIPCHK(hipDeviceSynchronize()); HIPCHK(hipFree(c->wt_op)); c->wt_op = nullptr; c->wt_cap = 0; }
-    HIPCHK(hipMalloc((void**)&c->wt_op, (size_t)K * N * sizeof(bf16_t)));
-    c->wt_cap = (size_t)K * N;
+    HIPCHK(hipMalloc((void**)&c->wt_op, (size_t)K * Npad * sizeof(bf16_t)));
+    c->wt_cap = (size_t)K * Npad;
   }
-  TRY(tile_param(w, IXT_BF16, c->wt_op, K, N, 0, st));
+  const bool wring = c->ring_wlayout && R >= c->ring_min_rows && K % IXT_KALIGN == 0 && (size_t)R * N <= c->part_floats;
+  if (wring) HIPCHK(hipMemsetAsync(c->wt_op, 0, (size_t)K * Npad * sizeof(bf16_t), st));
+  TRY(tile_param(w, IXT_BF16, c->wt_op, K, N, 0, st, 0, 0, wring ? 1 : 0));
   DotResult dr;
+  if (wring) {
+    GemmEpi e{};
+    e.out = c->part;
+    TRY(launch_ring(c, GEPI_F32, c->xt_op, c->wt_op, K, N, R, e, false, st, 1));
+    dr.slices = 1; dr.slice_stride = (size_t)R * N; dr.ntiles = N / 16;
+  } else
   TRY(launch_dot(c, c->xt_op, c->wt_op, K, N, R, c->part, c->part_floats, false, st, &dr));
   const size_t n = (size_t)R * N;
   hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
@@ -1190,7 +1221,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
-      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0},
+      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

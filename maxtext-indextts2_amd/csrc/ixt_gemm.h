@@ -10,7 +10,10 @@
 //     every one of them);
 //   * a block owns whole (tile, all chains) work items: the chain totals stay in registers and the epilogue consumes them on chip --
 //     no f32 slice leaves the chip except in the op-level / split forms.
-// Block = 4 waves as 2 x 2; wave tile = RB 16-row blocks x CT 16-column tiles; block tile = 32 RB rows x 32 CT columns.
+// Block = WR x WC waves; wave tile = RB 16-row blocks x CT 16-column tiles; block tile = 16 WR RB rows x 16 WC CT columns.
+// Measured with in-kernel stamps (tools/ring_probe.hip): an LDS-DMA issue holds its wave for about 75 cycles and MFMA issue is in order,
+// so one wave per SIMD runs load issue and MFMAs back to back (128 x 128 x 64-k chunk: 1 550 cycles); with TWO waves per SIMD (8-wave
+// blocks) one wave's MFMAs run under the other's load issue.
 //
 // Epilogues (EPI):
 //   GEPI_F32      f32 [slice][R][N] (op-level entry point, split-K form)
@@ -28,7 +31,7 @@ enum { GEPI_F32 = 0, GEPI_UNEMBED = 1, GEPI_RESID = 2, GEPI_SWIGLU = 3, GEPI_QKV
 
 struct GemmEpi {
   float* out;                                           // F32: [slices][R][N]; UNEMBED: rounded logits [R][N] or nullptr
-  float* amax_val; int32_t* amax_idx; ColRanges cr;     // UNEMBED: [R][2 ncolg]
+  float* amax_val; int32_t* amax_idx; ColRanges cr;     // UNEMBED: [R][WC ncolg]
   const bf16_t* h_in; bf16_t* h_out;                    // RESID: [R][N] row-major
   bf16_t* act;                                          // SWIGLU: [R][N/2] in xidx layout
   const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;   // QKV
@@ -42,17 +45,20 @@ __device__ __forceinline__ void ring_wait() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory");
 }
 
-//   grid = (8 ceil(ncolg / 8) zb, SPLIT ? chains : 1), block 256, dynamic LDS = NS (2 CT + 2 RB) KS KiB.
+//   grid = (8 ceil(ncolg / 8) zb, SPLIT ? chains : 1), block 64 WR WC, dynamic LDS = NS (WC CT + WR RB) KS KiB.
 //   Row groups of one column group are block ids b, b + 8, ..: same XCD, the weights meet in its L2.
-template <int RB, int CT, int KS, int NS, int EPI, int SPLIT>
-__global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
-                                                      int ncolg, int zb, GemmEpi e) {
-  constexpr int NWF = 2 * CT * KS;     // weight fragments of a chunk (2 CT tiles x KS k-steps)
-  constexpr int NXF = 2 * RB * KS;     // activation fragments (2 RB row blocks x KS k-steps)
+template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+                                                               int ncolg, int zb, int wring, GemmEpi e) {
+  constexpr int NW = WR * WC;          // waves
+  constexpr int TC = WC * CT;          // column tiles of a block
+  constexpr int TR = WR * RB;          // row blocks of a block
+  constexpr int NWF = TC * KS;         // weight fragments of a chunk
+  constexpr int NXF = TR * KS;         // activation fragments
   constexpr int NF = NWF + NXF;
-  constexpr int NJ = NF / 4;           // fragments a wave fetches per chunk
+  constexpr int NJ = NF / NW;          // fragments a wave fetches per chunk
   constexpr int D = NS - 1;            // chunks in flight
-  static_assert(NF % 4 == 0 && 16 % KS == 0 && (D - 1) * NJ < 64, "ring geometry");
+  static_assert(NF % NW == 0 && 16 % KS == 0 && (D - 1) * NJ < 64, "ring geometry");
   static_assert(EPI != GEPI_SWIGLU || CT % 2 == 0, "gate pairs need two tiles per wave");
   extern __shared__ __attribute__((aligned(16))) u32x4 st[];   // [NS][NF fragments][64 lanes]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -61,17 +67,19 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
   if (colg >= ncolg) return;                                    // whole block: no barrier is skipped
   const int nsteps = K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;
   const int nchunks = nsteps / KS;
-  const int wr = wave >> 1, wc = wave & 1;
+  const int wr = wave / WC, wc = wave % WC;
   const int r_in = lane & 15, cq = lane >> 4;
   const u32x4* src[NJ];
+  // weights: fragment order [tile][k-step] (wring == 0: the layout of the small-batch kernels) or the ring layout (r8frag)
+  const size_t wadv = wring ? (size_t)KS * 8 * 64 : (size_t)KS * 64;   // fragments (x 64 lanes) between two chunks of one tile
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int f = wave + 4 * j;
+    const int f = wave + NW * j;
     if (f < NWF) {
-      const int tile = min(colg * 2 * CT + f / KS, ntile - 1);    // past the end: a valid tile, results dropped
-      src[j] = wt + ((size_t)tile * nsteps + (f % KS)) * 64 + lane;
+      const int tile = wring ? colg * TC + f / KS : min(colg * TC + f / KS, ntile - 1);    // past the end: a valid (wring: padding) tile, results dropped
+      src[j] = wt + (wring ? r8frag(tile, f % KS, nsteps) : (size_t)tile * nsteps + (f % KS)) * 64 + lane;
     } else {
-      const int rb = min(rowg * 2 * RB + (f - NWF) / KS, nrbk - 1);
+      const int rb = min(rowg * TR + (f - NWF) / KS, nrbk - 1);
       src[j] = xt + ((size_t)rb * nsteps + ((f - NWF) % KS)) * 64 + lane;
     }
   }
@@ -81,8 +89,8 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
 #define IXT_RISSUE(CH_, SLOT_)                                                                                         \
   do {                                                                                                                 \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                     \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(CH_) * (KS * 64)), \
-                                       (__attribute__((address_space(3))) void*)(st + ((SLOT_) * NF + wave + 4 * j) * 64), 16, 0, 0); \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(CH_) * (wave + NW * j < NWF ? wadv : (size_t)KS * 64)), \
+                                       (__attribute__((address_space(3))) void*)(st + ((SLOT_) * NF + wave + NW * j) * 64), 16, 0, 0); \
   } while (0)
 #pragma unroll
   for (int c = 0; c < D; ++c)
@@ -93,7 +101,14 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
 #pragma unroll
     for (int b = 0; b < RB; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
   int slot = 0;                                                 // ring slot of chunk ch
+#ifdef IXT_RING_STAMPS   // diagnostic build (tools/ring_probe.hip): where an iteration spends its cycles; never defined in the product
+  unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_wait = 0, sum_bar = 0, sum_issue = 0, sum_comp = 0;
+#define IXT_STAMP(T_) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(T_) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define IXT_STAMP(T_) do { } while (0)
+#endif
   for (int ch = chb; ch < che; ++ch) {
+    IXT_STAMP(st0);
     // chunk ch has landed once at most min(D - 1, chunks after it) x NJ of this wave's younger loads are outstanding; the LDS reads
     // of the previous chunk are retired (lgkmcnt(0)) before the barrier lets any wave refill their slot
     const int rem = che - 1 - ch;
@@ -102,23 +117,41 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
     else if (D > 1 && rem == 1) ring_wait<(D > 1 ? 1 : 0) * NJ>();
     else if (D > 3 && rem == 3) ring_wait<(D > 3 ? 3 : 0) * NJ>();
     else ring_wait<0>();
+    IXT_STAMP(st1);
     __builtin_amdgcn_s_barrier();
-    if (ch + D < che) {
-      const int fill = slot == 0 ? NS - 1 : slot - 1;           // the slot of chunk ch - 1 = that of chunk ch + D
-      IXT_RISSUE(ch + D, fill);
-    }
+    IXT_STAMP(st2);
+    // All LDS reads of the chunk first (their latency then runs under the issue of the refill loads), then the MFMAs in groups of RB
+    // with the NJ refill loads of chunk ch + D dealt between the groups: an LDS-DMA issue costs the wave about 50 cycles, a group of
+    // 4 MFMAs keeps the matrix pipe busy for 64, so the refill rides under the MFMAs instead of in front of them.
     const u32x4* sb = st + (size_t)slot * NF * 64;
+    bf16x8 wf[KS][CT], xf[KS][RB];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 wf[CT], xf[RB];
 #pragma unroll
-      for (int i = 0; i < CT; ++i) wf[i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * KS + ks) * 64 + lane]);
+      for (int i = 0; i < CT; ++i) wf[ks][i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * KS + ks) * 64 + lane]);
 #pragma unroll
-      for (int b = 0; b < RB; ++b) xf[b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * RB + b) * KS + ks) * 64 + lane]);
+      for (int b = 0; b < RB; ++b) xf[ks][b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * RB + b) * KS + ks) * 64 + lane]);
+    }
+    IXT_STAMP(st3);
+    const bool refill = ch + D < che;
+    const int fill = slot == 0 ? NS - 1 : slot - 1;             // the slot of chunk ch - 1 = that of chunk ch + D
+    constexpr int NG = KS * CT;                                 // MFMA groups of an iteration
 #pragma unroll
-      for (int i = 0; i < CT; ++i)
+    for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-        for (int b = 0; b < RB; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[b], acc[i][b], 0, 0, 0);
+      for (int i = 0; i < CT; ++i) {
+#pragma unroll
+        for (int b = 0; b < RB; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][b], acc[i][b], 0, 0, 0);
+        const int gi = ks * CT + i;
+        if (refill) {
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            if (j * NG / NJ == gi)                              // load j rides behind group j NG / NJ
+              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[j] + (size_t)(ch + D) * (wave + NW * j < NWF ? wadv : (size_t)KS * 64)),
+                                               (__attribute__((address_space(3))) void*)(st + (fill * NF + wave + NW * j) * 64), 16, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (((ch + 1) % CPC) == 0 || ch + 1 == che) {               // a 512-k chain is complete
 #pragma unroll
@@ -127,7 +160,18 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
         for (int b = 0; b < RB; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
     }
     slot = slot + 1 == NS ? 0 : slot + 1;
+#ifdef IXT_RING_STAMPS
+    IXT_STAMP(st4);
+    sum_wait += st1 - st0; sum_bar += st2 - st1; sum_issue += st3 - st2; sum_comp += st4 - st3;
+#endif
   }
+#ifdef IXT_RING_STAMPS
+  if (lane == 0 && e.amax_val != nullptr) {   // the probe passes a buffer of its own here: [block][wave][4] cycle sums
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(e.amax_val) + ((size_t)bx * NW + wave) * 4;
+    dbg[0] = sum_wait; dbg[1] = sum_bar; dbg[2] = sum_issue; dbg[3] = sum_comp;
+  }
+#endif
+#undef IXT_STAMP
 #undef IXT_RISSUE
 
   // ---------------------------------------------------------------- epilogues
@@ -135,10 +179,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
     float* out = e.out + (SPLIT ? (size_t)blockIdx.y * R * N : 0);
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-      const int tile = colg * 2 * CT + wc * CT + i;
+      const int tile = colg * TC + wc * CT + i;
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        const int row = (rowg * 2 * RB + wr * RB + b) * 16 + r_in;
+        const int row = (rowg * TR + wr * RB + b) * 16 + r_in;
         if (tile < ntile && row < R)
           *reinterpret_cast<float4*>(out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[i][b][0], tot[i][b][1], tot[i][b][2], tot[i][b][3]);
       }
@@ -146,12 +190,12 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
   } else if constexpr (EPI == GEPI_UNEMBED) {
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      const int row = (rowg * 2 * RB + wr * RB + b) * 16 + r_in;
+      const int row = (rowg * TR + wr * RB + b) * 16 + r_in;
       float bv = -INFINITY;
       int bi = 0x7fffffff;
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
-        const int tile = colg * 2 * CT + wc * CT + i;
+        const int tile = colg * TC + wc * CT + i;
         if (tile < ntile) {
           float v[4];
 #pragma unroll
@@ -169,17 +213,17 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
       }
       if (cq == 0 && row < R) {
-        e.amax_val[(size_t)row * (2 * ncolg) + colg * 2 + wc] = bv;
-        e.amax_idx[(size_t)row * (2 * ncolg) + colg * 2 + wc] = bi;
+        e.amax_val[(size_t)row * (WC * ncolg) + colg * WC + wc] = bv;
+        e.amax_idx[(size_t)row * (WC * ncolg) + colg * WC + wc] = bi;
       }
     }
   } else if constexpr (EPI == GEPI_RESID) {
 #pragma unroll
     for (int i = 0; i < CT; ++i) {
-      const int tile = colg * 2 * CT + wc * CT + i;
+      const int tile = colg * TC + wc * CT + i;
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        const int row = (rowg * 2 * RB + wr * RB + b) * 16 + r_in;
+        const int row = (rowg * TR + wr * RB + b) * 16 + r_in;
         if (tile < ntile && row < R) {
           const size_t o = (size_t)row * N + tile * 16 + cq * 4;
           const uint2 hv = *reinterpret_cast<const uint2*>(e.h_in + o);
@@ -194,10 +238,10 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
     const int F = N >> 1;
 #pragma unroll
     for (int i = 0; i < CT; i += 2) {
-      const int tile = colg * 2 * CT + wc * CT + i;             // even: wi_0 tile tile/2; tile + 1: wi_1 tile tile/2
+      const int tile = colg * TC + wc * CT + i;             // even: wi_0 tile tile/2; tile + 1: wi_1 tile tile/2
 #pragma unroll
       for (int b = 0; b < RB; ++b) {
-        const int row = (rowg * 2 * RB + wr * RB + b) * 16 + r_in;
+        const int row = (rowg * TR + wr * RB + b) * 16 + r_in;
         if (tile + 1 < ntile && row < R) {
           const int f0 = (tile >> 1) * 16 + cq * 4;
           bf16_t o[4];
@@ -215,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
     const int QN = g.nq * g.hd, KN = g.nkv * g.hd;
 #pragma unroll
     for (int b = 0; b < RB; ++b) {
-      const int row = (rowg * 2 * RB + wr * RB + b) * 16 + r_in;
+      const int row = (rowg * TR + wr * RB + b) * 16 + r_in;
       const bool row_ok = row < R;
       const int pos = row_ok ? e.row_pos[row] : 0;
       const bool wr_kv = row_ok && e.row_active[row] != 0;
@@ -224,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void k_gemm_ring(const u32x4* __restrict__ 
       const int tok = pos % g.P;
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
-        const int tile = colg * 2 * CT + wc * CT + i;
+        const int tile = colg * TC + wc * CT + i;
         const int col0 = tile * 16;
         float v[4];
 #pragma unroll

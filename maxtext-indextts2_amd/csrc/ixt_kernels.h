@@ -59,6 +59,15 @@ __host__ __device__ __forceinline__ size_t xidx(int r, int k, int K) {
   return (size_t)(r >> 4) * K * 16 + (((size_t)(k >> 5) * 4 + ((k & 31) >> 3)) * 16 + (r & 15)) * 8 + (k & 7);
 }
 __host__ __device__ __forceinline__ size_t widx(int k, int n, int K) { return xidx(n, k, K); }
+// Ring layout of a weight matrix (the LDS-ring GEMM's operand order, ixt_gemm.h): [n/128][k/64][(n%128)/16][(k%64)/32] fragments of 1 KiB,
+// i.e. the 16 KiB a 128-column block needs for one 64-k chunk are contiguous and a block reads its whole operand as ONE sequential
+// stream (DRAM row locality); columns are padded to a multiple of 128.
+__host__ __device__ __forceinline__ size_t r8frag(int tile, int step, int nsteps) {
+  return ((size_t)(tile >> 3) * (nsteps >> 1) + (step >> 1)) * 16 + (tile & 7) * 2 + (step & 1);
+}
+__host__ __device__ __forceinline__ size_t r8idx(int k, int n, int K) {
+  return r8frag(n >> 4, k >> 5, K >> 5) * 512 + ((size_t)((k & 31) >> 3) * 16 + (n & 15)) * 8 + (k & 7);
+}
 // Column of feature i (0..hd-1) of a Q or K head inside the head's hd columns of the fused QKV kernel: 16-column tile j holds
 // features 8j..8j+7 and half+8j..half+8j+7, so the two RoPE partners (i, i + half) of a feature share a tile (ixt_gemm.h, GEPI_QKV).
 __host__ __device__ __forceinline__ int qk_col(int i, int half) {
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm(const u32x4* __restrict__ xt, c
 //   mode 2: the fused MLP gate kernel: tile j of this source becomes column tile 2 j + n_off (n_off = 0: wi_0, 1: wi_1), so that a
 //           wave holds both gates of a feature (ixt_gemm.h, GEPI_SWIGLU; k_swiglu_part reads the same layout)
 template <typename T>
-__global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off, int mode, int hd) {
+__global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, int K, int ncols, int n_off, int mode, int hd, int ring) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)K * ncols) return;
   const int k = (int)(i / ncols), n = (int)(i % ncols);
@@ -499,7 +508,7 @@ __global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, in
   if (mode == 1) col = n_off + (n / hd) * hd + qk_col(n % hd, hd >> 1);
   else if (mode == 2) col = ((n >> 4) * 2 + n_off) * 16 + (n & 15);
   else col = n_off + n;
-  dst[widx(k, col, K)] = v;
+  dst[ring ? r8idx(k, col, K) : widx(k, col, K)] = v;
 }
 
 // x [R][K] row-major bf16 -> the dot kernel's x layout (op-level entry point only; the model's producers write it directly)

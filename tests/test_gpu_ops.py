@@ -114,19 +114,22 @@ def test_dot_gemm_split_kernel(ctx, R, K, N):
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"gemm_split_min_blocks", 300))
 
 
+@pytest.mark.parametrize("wlayout", [0, 1])
 @pytest.mark.parametrize("cfg_id", [1, 2, 3])
-@pytest.mark.parametrize("R,K,N", [(128, 1024, 256), (250, 1152, 272), (200, 2048, 144), (129, 640, 16), (256, 512, 80), (130, 128, 528)])
-def test_dot_ring_kernel(ctx, cfg_id, R, K, N):
+@pytest.mark.parametrize("R,K,N", [(128, 1024, 256), (250, 1152, 256), (200, 2048, 144), (129, 640, 16), (256, 512, 80), (130, 128, 496)])
+def test_dot_ring_kernel(ctx, cfg_id, R, K, N, wlayout):
   """The LDS-ring GEMM (csrc/ixt_gemm.h; the default from 128 rows), f32 epilogue, each of its three tiles forced in turn
   (128 x 128, 128 x 64, 64 x 32): ragged last row group / row block, one chain, a short last chain, fewer chunks than ring slots
-  (K = 128), partial column groups."""
+  (K = 128), partial column groups; weights in the small-batch kernels' fragment order and in the ring layout."""
   eng = ctx["eng"]
   H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_cfg", cfg_id))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_wlayout", wlayout))
   try:
     rng = np.random.default_rng(R + K + N + cfg_id)
     _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
   finally:
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_cfg", 0))
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_wlayout", 0))
 
 
 @pytest.mark.parametrize("R,K,N", [(128, 1024, 128), (250, 1152, 64), (200, 2048, 80)])

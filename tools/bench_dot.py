@@ -27,7 +27,8 @@ def main():
   # kernel variants: (label, {option: value}); the ring GEMM (csrc/ixt_gemm.h) is the default from 128 rows
   variants = [("default", {})]
   if max(rows) >= 128:
-    variants += [("ring 128x128", {"ring_cfg": 1}), ("ring 128x64", {"ring_cfg": 2}), ("ring 64x32", {"ring_cfg": 3}), ("ring split", {"ring_split": 1}),
+    variants += [("ring 128x128", {"ring_cfg": 1}), ("ring 128x64", {"ring_cfg": 2}), ("ring 64x32", {"ring_cfg": 3}), ("ring split", {"ring_split": 1}), ("ring 128x128 ring-layout W", {"ring_cfg": 1, "ring_wlayout": 1}),
+                 ("ring 128x64 ring-layout W", {"ring_cfg": 2, "ring_wlayout": 1}), ("ring 64x32 ring-layout W", {"ring_cfg": 3, "ring_wlayout": 1}),
                  ("k_gemm / k_dotb (round 1)", {"ring_min_rows": 1 << 30})]
   for R in rows:
    for label, opts in (variants if R >= 128 else variants[:1]):
@@ -54,10 +55,10 @@ def main():
       lib.ixt_timing_get(eng._ctx, b"dot", ctypes.byref(avg), ctypes.byref(n), ctypes.byref(bpl))
       lib.ixt_timing_enable(eng._ctx, 0)
       wbytes = K * N * 2
-      print(f"R={R:3d} {name:8s} K={K:5d} N={N:6d}  {avg.value:8.2f} us  weights {wbytes/avg.value/1e6:7.1f} GB/s  (launches {n.value})", flush=True)
+      print(f"R={R:3d} {name:8s} K={K:5d} N={N:6d}  {avg.value:8.2f} us  weights {wbytes/avg.value/1e6:7.2f} TB/s  (launches {n.value})", flush=True)
       del ws
     for k in opts:
-      H.lib.check(lib.ixt_set_option(eng._ctx, k.encode(), {"ring_cfg": 0, "ring_split": 0, "ring_min_rows": 128}[k]))
+      H.lib.check(lib.ixt_set_option(eng._ctx, k.encode(), {"ring_cfg": 0, "ring_split": 0, "ring_min_rows": 128, "ring_wlayout": 0}[k]))
 
 
 if __name__ == "__main__":
