@@ -2,11 +2,12 @@
 """Headline benchmark: audio tokens / second over prefill + decode of the 1B IndexTTS2-style decoder (BASELINE.json
 configs[1], "C2"), data-parallel over N GPUs of one node (one process per GPU, no collective on the data path).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts N rank processes itself, before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 256) utterances per GPU,
-each a 256-token prompt (4 s reference speech + 128-char text) prefilled into its slot, then
+each a 256-token prompt (4 s reference speech + 128-char text) prefilled -- `--prefill-pack` (default 8)
+prompts per pass over the weights through the engine's prefill_concat / insert_partial (maxengine.py:719-836, 1206-1318) -- then
 `--decode-steps` (default 1024) greedy generate calls for all slots.  Tokens counted = generated audio tokens
 including the first one from prefill (decode.py:162-178: T-P generate calls yield T-P+1 tokens per utterance).
 Rank 0 prints ONE JSON line.
@@ -24,15 +25,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
   sys.path.insert(0, ROOT)
 
-import numpy as np
-import torch
+_T0 = time.time()
+
+
+def _log(msg):
+  """Progress on stderr (stdout carries the one JSON line)."""
+  print(f"[bench +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
 
 HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md "HBM3E peak BW 8.0 TB/s spec"
 MFMA_BF16_PEAK = 2.5e15    # FLOP/s dense bf16 (same guide)
-MFMA_F32_PEAK = 157.3e12   # FLOP/s f32-input MFMA (same guide, "Peak FP32 (matrix)")
 
 
-def parse():
+def parse(argv=None):
   ap = argparse.ArgumentParser()
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2)
@@ -40,16 +45,32 @@ def parse():
   ap.add_argument("--batch", type=int, default=256, help="utterances (decode slots) per GPU")
   ap.add_argument("--decode-steps", type=int, default=1024)
   ap.add_argument("--prefill-len", type=int, default=256)
+  ap.add_argument("--prefill-pack", type=int, default=8, help="prompts per packed prefill (prefill_concat); 1 = one prefill call per utterance")
   ap.add_argument("--model", default="indextts2-1b")
   ap.add_argument("--no-graph", action="store_true")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
-  ap.add_argument("--cpu-decode-steps", type=int, default=4)
-  return ap.parse_args()
+  ap.add_argument("--no-batch-rows", action="store_true", help="skip the B=1 / B=8 rows of SURVEY.md section 8(d)")
+  ap.add_argument("--no-detail", action="store_true", help="skip the separate prefill-only / decode-only pass (profiling runs)")
+  ap.add_argument("--cpu-batch", type=int, default=16, help="utterances of the CPU baseline sample")
+  ap.add_argument("--cpu-slice-steps", type=int, default=2)
+  ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (the GPU box's CPU share for one GPU is 16)")
+  ap.add_argument("--sync-every", type=int, default=0, help="synchronise the stream every N engine calls (profiling runs: bounds the launch backlog)")
+  ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU rehearsal)")
+  ap.add_argument("--stub-engine", action="store_true", help="CPU rehearsal of the multi-process plumbing (tests/test_dp_cpu.py): no GPU, no model")
+  return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------------------------- model numbers
+def model_numbers(cfg):
+  E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size, cfg.num_decoder_layers)
+  body = L * (E * (Q * D + 2 * KV * D) + Q * D * E + 2 * E * F + F * E)
+  return {"body_params": body, "unembed_params": E * V, "kv_bytes_per_token": 2 * KV * D * 2 * L}
 
 
 def gpu_weights(cfg, device, seed=0):
   """Random-init weights of the architecture, drawn on the GPU (fast); same distributions as synth.synth_weights."""
+  import torch
   synth = importlib.import_module("maxtext-indextts2_amd.synth")
   g = torch.Generator(device=device)
   g.manual_seed(seed)
@@ -78,235 +99,332 @@ def gpu_weights(cfg, device, seed=0):
   return w
 
 
-def model_numbers(cfg):
-  E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size, cfg.num_decoder_layers)
-  body = L * (E * (Q * D + 2 * KV * D) + Q * D * E + 2 * E * F + F * E)
-  unembed = E * V
-  kv_bytes_per_token = 2 * KV * D * 2 * L
-  return {"body_params": body, "unembed_params": unembed, "kv_bytes_per_token": kv_bytes_per_token}
+# ------------------------------------------------------------------------------------------------------------------- the workload
+class Workload:
+  """One GPU's share: B utterances through the engine's own prefill / insert / generate surface."""
+
+  def __init__(self, eng, params, prompts_dev, decode_steps, pack, sync_every=0, sync=None):
+    self.eng, self.params, self.prompts, self.decode_steps = eng, params, prompts_dev, decode_steps
+    self.pack, self.sync_every, self.sync, self.calls = max(1, pack), sync_every, sync, 0
+    self._packed = None
+
+  def _tick(self):
+    self.calls += 1
+    if self.sync_every and self.sync and self.calls % self.sync_every == 0:
+      self.sync()
+
+  def _packed_inputs(self):
+    """Device arrays of each packed prefill, built once (they are inputs, like the prompts themselves)."""
+    if self._packed is None:
+      import numpy as np
+      import torch
+      self._packed = []
+      B = len(self.prompts)
+      for s0 in range(0, B, self.pack):
+        group = self.prompts[s0:s0 + self.pack]
+        lens = np.array([tl for _, tl in group], np.int32)
+        dev = group[0][0].device
+        toks = torch.cat([t[:tl] for t, tl in group])
+        pos = torch.cat([torch.arange(tl, dtype=torch.int32, device=dev) for tl in lens])
+        seg = torch.cat([torch.full((int(tl),), i + 1, dtype=torch.int32, device=dev) for i, tl in enumerate(lens)])
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        self._packed.append((toks, pos, seg, starts, lens, np.arange(s0, s0 + len(group))))
+    return self._packed
+
+  def prefill_all(self, ds):
+    eng = self.eng
+    if self.pack == 1:
+      for s, (t, tl) in enumerate(self.prompts):
+        pre, _ = eng.prefill(params=self.params, padded_tokens=t, true_length=tl, slot=s)
+        ds = eng.insert(pre, ds, s)
+        self._tick()
+      return ds
+    for toks, pos, seg, starts, lens, slots in self._packed_inputs():
+      cache, pres, _ = eng.prefill_concat(params=self.params, padded_tokens=toks, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts,
+                                          true_lengths=lens, num_prompts=len(lens))
+      ds = eng.insert_partial(pres, ds, cache, slots, start_indices=starts, num_prompts=len(lens), seq_len=int(lens.max()))
+      self._tick()
+    return ds
+
+  def decode_all(self, ds, steps=None, collect=None):
+    for _ in range(self.decode_steps if steps is None else steps):
+      ds, res = self.eng.generate(self.params, ds)
+      if collect is not None:
+        collect.append(res.data)
+      self._tick()
+    return ds
+
+  def release_all(self):
+    for s in range(len(self.prompts)):
+      self.eng.release_pages(s)
+
+  def one_pass(self):
+    ds = self.prefill_all(self.eng.init_decode_state())
+    self.decode_all(ds)
+    self.release_all()
+
+
+class _StubEngine:
+  """CPU stand-in with the engine's call surface (tests/test_dp_cpu.py: the multi-process plumbing of this file without a GPU)."""
+
+  def __init__(self, batch):
+    import torch
+    self.B, self.torch = batch, torch
+
+  def init_decode_state(self):
+    return {"tokens": self.torch.zeros((self.B, 1), dtype=self.torch.int32)}
+
+  def prefill(self, *, params, padded_tokens, true_length, slot):
+    return {"tokens": self.torch.tensor([[int(padded_tokens[0]) % 97]])}, None
+
+  def insert(self, pre, ds, slot):
+    ds["tokens"][slot] = pre["tokens"][0]
+    return ds
+
+  def generate(self, params, ds):
+    time.sleep(0.0005)
+    ds["tokens"] = (ds["tokens"] * 31 + 7) % 1009
+
+    class R:
+      data = self.torch.cat([ds["tokens"], self.torch.ones_like(ds["tokens"]), self.torch.zeros_like(ds["tokens"])], dim=1)
+    return ds, R
+
+  def release_pages(self, slot):
+    pass
+
+
+# ------------------------------------------------------------------------------------------------------------------- one rank
+def make_engine(args, pyconfig, maxengine, B, device_weights=None):
+  P, T = args.prefill_len, args.prefill_len + args.decode_steps
+  pages_per_seq = (T + 31) // 32
+  pack = max(1, min(args.prefill_pack, B))
+  cfg = pyconfig.initialize(
+      ["bench", os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")], model_name=args.model, attention="paged", scan_layers=False,
+      per_device_batch_size=float(B), max_prefill_predict_length=P, max_target_length=T, pagedattn_tokens_per_page=32,
+      pagedattn_num_pages=(B + (pack if pack > 1 else 0)) * pages_per_seq + 1, ixt_use_hip_graph=not args.no_graph, run_name="bench",
+      ixt_staging_groups=pack if pack > 1 else 0, ixt_max_packed_rows=pack * P if pack > 1 else 0)
+  eng = maxengine.MaxEngine(cfg)
+  return cfg, eng, pack
+
+
+def run_rank(args):
+  import numpy as np
+  import torch
+  dp = importlib.import_module("maxtext-indextts2_amd.dp")
+  rank, local_rank, world = dp.env_world()
+  if world != args.gpus:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch N ranks (python bench.py --gpus N does it itself)")
+  stub = args.stub_engine
+  device = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+  if not stub:
+    torch.cuda.set_device(local_rank)
+  if world > 1:
+    dp.init(args.backend, None if stub else device)
+  sync_dev = (lambda: None) if stub else torch.cuda.synchronize
+  B, P = args.batch, args.prefill_len
+  synth = importlib.import_module("maxtext-indextts2_amd.synth")
+
+  if stub:
+    cfg, eng, params, weights, pack = None, _StubEngine(B), None, None, 1
+    prompts = [(np.full((P,), rank * B + s, np.int32), P) for s in range(B)]
+    prompts_dev = [(torch.from_numpy(t), tl) for t, tl in prompts]
+  else:
+    pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
+    maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
+    cfg, eng, pack = make_engine(args, pyconfig, maxengine, B)
+    weights = gpu_weights(cfg, device, seed=0)
+    params = eng.load_params(params=weights)
+    # distinct utterances per rank and slot: seeds 1234 + global utterance index
+    prompts = [synth.synth_prompt(cfg.vocab_size, P, 1234 + rank * B + s) for s in range(B)]
+    prompts_dev = [(torch.from_numpy(t).to(device), tl) for t, tl in prompts]
+  wl = Workload(eng, params, prompts_dev, args.decode_steps, pack, args.sync_every, sync_dev)
+
+  _log(f"rank {rank}: engine and weights ready")
+  # ---- the timed region: W warm-up passes, then exactly K passes between barriers; MAX over ranks (dp.timed_region)
+  elapsed = dp.timed_region(wl.one_pass, args.steps, args.warmup, sync_dev, None if stub else device)
+  tokens_per_pass = B * (args.decode_steps + 1)
+  value = tokens_per_pass * args.steps * world / elapsed
+  _log(f"rank {rank}: timed region done: {elapsed / args.steps * 1e3:.1f} ms per pass")
+
+  out = {"metric": "audio-tokens/sec (prefill+decode) @ 1B IndexTTS2", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+         "dtype": "bf16 (bf16 matrix-core dots, f32 accumulate; f32 fma chains in attention/norms)", "data": "synthetic",
+         "config": {"workload": f"C2 {args.model}: {P}-token prefill -> {args.decode_steps} greedy audio-token decode steps, {B} utterances/GPU, "
+                                f"paged KV (32 tok/page), {pack} prompts per packed prefill",
+                    "utterances_per_gpu": B, "prefill_len": P, "decode_steps": args.decode_steps, "parallelism": f"dp{world}", "hip_graph": not args.no_graph,
+                    "prefill_pack": pack},
+         "per_gpu_tokens_per_s": value / world}
+  if stub:
+    if rank == 0:
+      print(json.dumps(out), flush=True)
+    dp.finish()
+    return
+
+  nums = model_numbers(cfg)
+  if rank == 0:
+    out["detail"] = {} if args.no_detail else detail_split(args, wl, eng, nums, B, P)
+    _log("prefill / decode split done")
+    out["roofline"] = None if args.no_roofline else roofline(args, wl, eng, cfg, nums, prompts, B)
+    _log("live roofline done")
+    if not args.no_batch_rows:
+      out["detail"]["batch_rows"] = []
+      for b in (1, 8):
+        out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
+        _log(f"batch row B={b} done")
+    out["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(args, cfg, weights, prompts)
+    _log("cpu baseline done")
+    print(json.dumps(out), flush=True)
+  dp.finish()
+
+
+def detail_split(args, wl, eng, nums, B, P):
+  """Prefill-only and decode-only times of one more pass (rank 0 reporting detail)."""
+  import torch
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  ds = wl.prefill_all(eng.init_decode_state())
+  torch.cuda.synchronize()
+  t_prefill = time.perf_counter() - t1
+  t2 = time.perf_counter()
+  wl.decode_all(ds)
+  torch.cuda.synchronize()
+  t_decode = time.perf_counter() - t2
+  wl.release_all()
+  ms_step = t_decode / args.decode_steps * 1e3
+  mean_ctx = P + args.decode_steps / 2.0
+  step_bytes = (nums["body_params"] + nums["unembed_params"]) * 2 + B * mean_ctx * nums["kv_bytes_per_token"] + B * nums["kv_bytes_per_token"]
+  step_flops = B * 2.0 * (nums["body_params"] + nums["unembed_params"]) + B * mean_ctx * nums["kv_bytes_per_token"]
+  prefill_flops = 2.0 * P * nums["body_params"] + 4.0 * 16 * 128 * 16 * P * P / 2 + 2.0 * nums["unembed_params"]   # SURVEY 8(d): last-row logits only
+  return {"prefill_ms_per_utterance": t_prefill / B * 1e3, "prefill_mfu": prefill_flops / (t_prefill / B) / MFMA_BF16_PEAK,
+          "decode_ms_per_step": ms_step, "decode_tokens_per_s": B / (ms_step * 1e-3),
+          "decode_step_algorithmic_bytes": step_bytes, "decode_hbm_frac": step_bytes / (ms_step * 1e-3) / HBM_PEAK,
+          "decode_mfu": step_flops / (ms_step * 1e-3) / MFMA_BF16_PEAK}
+
+
+def roofline(args, wl, eng, cfg, nums, prompts, B):
+  """Roofline of the dominant kernel, measured live with HIP events on the launch stream (eager launches of 16 decode steps in the middle
+  of the decode range).  Two kernel families carry (almost) every HBM byte of a decode step: the one-launch decode attention (K/V pages)
+  and the canonical dot (weights).  The one with the larger share of the step is reported; the other rides along in "other"."""
+  import ctypes
+  import torch
+  lib = eng.lib
+  ds = wl.prefill_all(eng.init_decode_state())
+  mid = max(0, args.decode_steps // 2 - 8)
+  ds = wl.decode_all(ds, steps=mid)
+  torch.cuda.synchronize()
+  lib.ixt_timing_enable(eng._ctx, 1)
+  lib.ixt_timing_reset(eng._ctx)
+  nmeas = 16
+  ds = wl.decode_all(ds, steps=nmeas)
+
+  def fam(name):
+    avg_us, n, bpl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
+    lib.ixt_timing_get(eng._ctx, name, ctypes.byref(avg_us), ctypes.byref(n), ctypes.byref(bpl))
+    return avg_us.value, int(n.value), bpl.value
+  dot_us, dot_n, dot_bpl = fam(b"dot_decode")
+  att_us, att_n, _ = fam(b"attn_decode")
+  lib.ixt_timing_enable(eng._ctx, 0)
+  wl.release_all()
+  # contexts during the measured steps: every utterance has true_length tl_s + mid + i + 1 keys at measured step i
+  ctx_sum = sum(tl + mid + (nmeas + 1) / 2.0 for (_, tl) in prompts)
+  kv_layer = nums["kv_bytes_per_token"] / cfg.num_decoder_layers                 # K+V bytes per token per layer (8 192 at C2)
+  att_bpl = ctx_sum * kv_layer + B * kv_layer                                    # read every cached key/value once + the new one
+  build_id = lib.ixt_build_id().decode()
+  traffic, traffic_src, mfma, stale = None, None, None, None
+  pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
+  if os.path.exists(pmc):
+    try:
+      pj = json.load(open(pmc))
+      if pj.get("batch") == B and pj.get("model") == args.model:
+        if pj.get("build_id") == build_id:      # counters of THIS build only
+          traffic, traffic_src, mfma = pj.get("attn_hbm_bytes_per_launch"), pj.get("source"), pj.get("mfma")
+        else:
+          stale = f"profiles/r02_pmc.json was measured on build {pj.get('build_id')}, this is {build_id}"
+    except Exception:  # pylint: disable=broad-except
+      pass
+  dot = {"kernel": "k_gemm_ring / k_gemm / k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
+         "achieved": dot_bpl / (dot_us * 1e-6) / 1e9 if dot_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": dot_us, "launches": dot_n,
+         "algorithmic_bytes_per_launch": dot_bpl, "us_per_step": dot_us * dot_n / nmeas}
+  att = {"kernel": "k_attn_decode (one launch per layer: scores, softmax, PV over the paged KV cache)", "bound": "hbm",
+         "achieved": att_bpl / (att_us * 1e-6) / 1e9 if att_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": att_us, "launches": att_n,
+         "algorithmic_bytes_per_launch": att_bpl, "us_per_step": att_us * att_n / nmeas, "mean_context": ctx_sum / B}
+  for d in (dot, att):
+    d["peak"] = HBM_PEAK / 1e9
+    d["frac"] = d["achieved"] / d["peak"]
+  main_k, other = (att, dot) if att["us_per_step"] >= dot["us_per_step"] else (dot, att)
+  r = dict(main_k)
+  r["traffic"], r["traffic_source"], r["build_id"] = traffic, traffic_src, build_id
+  if stale:
+    r["traffic_stale"] = stale
+  if mfma:
+    r["mfma_utilisation"] = mfma
+  r["other"] = other
+  return r
+
+
+def batch_row(args, b, weights, prompts_dev, nums):
+  """the same model at B = 1 (latency) and B = 8 utterances per GPU against the HBM bounds of BASELINE.md section 4."""
+  import torch
+  pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
+  maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
+  sub = argparse.Namespace(**vars(args))
+  sub.prefill_pack = 1
+  cfg, eng, _ = make_engine(sub, pyconfig, maxengine, b)
+  params = eng.load_params(params=weights)
+  wl = Workload(eng, params, prompts_dev[:b], args.decode_steps, 1)
+  wl.one_pass()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  ds = wl.prefill_all(eng.init_decode_state())
+  torch.cuda.synchronize()
+  t1 = time.perf_counter()
+  wl.decode_all(ds)
+  torch.cuda.synchronize()
+  t2 = time.perf_counter()
+  wl.release_all()
+  del eng
+  ms_step = (t2 - t1) / args.decode_steps * 1e3
+  mean_ctx = args.prefill_len + args.decode_steps / 2.0
+  step_bytes = (nums["body_params"] + nums["unembed_params"]) * 2 + b * (mean_ctx + 1) * nums["kv_bytes_per_token"]
+  bound = b / (step_bytes / HBM_PEAK)
+  return {"utterances": b, "tokens_per_s": b * (args.decode_steps + 1) / (t2 - t0), "decode_ms_per_step": ms_step, "decode_tokens_per_s": b / (ms_step * 1e-3),
+          "prefill_ms_per_utterance": (t1 - t0) / b * 1e3, "decode_hbm_frac": step_bytes / (ms_step * 1e-3) / HBM_PEAK,
+          "hbm_bound_tokens_per_s": bound}
+
+
+def cpu_baseline(args, cfg, weights, prompts):
+  """The reference ALGORITHM on this host's CPU cores (oracle/ref_algo_cpu.py: dense two-segment cache, both full buffers read at every step,
+  [1, P, V] prefill logits, bf16 values / f32 accumulation), on a bounded sample of the workload.  JAX (the north star's `jax.devices('cpu')`)
+  is not installed anywhere in this pipeline; this torch-CPU restatement is the labelled stand-in of BASELINE.md section 3."""
+  import numpy as np
+  import torch
+  from oracle import ref_algo_cpu as RA
+  host_w = {k: v.detach().contiguous().view(torch.int16).cpu().numpy().view(np.uint16) for k, v in weights.items()}
+  cb = max(1, min(args.cpu_batch, args.batch))
+  # the GPU box gives one GPU's job 16 CPUs whatever os.cpu_count() says: more threads than that only thrash
+  threads = min(args.cpu_threads, os.cpu_count() or 1)
+  _log(f"cpu baseline: {cb} utterances on {threads} threads")
+  r = RA.measure(cfg, host_w, prompts, cb, args.prefill_len, args.decode_steps, slice_steps=args.cpu_slice_steps, threads=threads, log=_log)
+  model = ""
+  try:
+    model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo", encoding="utf-8") if l.startswith("model name")][0]
+  except Exception:  # pylint: disable=broad-except
+    pass
+  r.update({"host_cpus": os.cpu_count(), "cpu_model": model,
+            "sample": f"torch-cpu restatement of the reference algorithm (JAX unavailable), {r['matmul']} matmul, {r['cores']} threads: {cb} utterances, one "
+                      f"{args.prefill_len}-token prefill timed ({r['prefill_s_per_utterance']:.2f} s, charged {cb} times) + {args.cpu_slice_steps}-step decode slices at "
+                      f"three ring positions ({', '.join(f'{s:.3f}' for s in r['decode_slices_s_per_step'])} s/step), integrated over {args.decode_steps} steps"})
+  return r
 
 
 def main():
   args = parse()
-  rank = int(os.environ.get("RANK", "0"))
-  local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-  world = int(os.environ.get("WORLD_SIZE", "1"))
-  if world > 1:
-    import torch.distributed as dist
-    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-  torch.cuda.set_device(local_rank)
-  device = torch.device("cuda", local_rank)
-
-  pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
-  maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
-  synth = importlib.import_module("maxtext-indextts2_amd.synth")
-  B, P, T = args.batch, args.prefill_len, args.prefill_len + args.decode_steps
-  pages_per_seq = (T + 31) // 32
-  cfg = pyconfig.initialize(
-      ["bench", os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")], model_name=args.model, attention="paged", scan_layers=False,
-      per_device_batch_size=float(B), max_prefill_predict_length=P, max_target_length=T, pagedattn_tokens_per_page=32,
-      pagedattn_num_pages=B * pages_per_seq + 1, ixt_use_hip_graph=not args.no_graph, run_name="bench")
-  eng = maxengine.MaxEngine(cfg)
-  weights = gpu_weights(cfg, device, seed=0)
-  params = eng.load_params(params=weights)
-  # distinct utterances per rank and slot: seeds 1234 + global utterance index
-  prompts = [synth.synth_prompt(cfg.vocab_size, P, 1234 + rank * B + s) for s in range(B)]
-  prompts_dev = [(torch.from_numpy(t).to(device), tl) for t, tl in prompts]
-
-  def one_pass(collect=False):
-    prefixes = []
-    for s, (t, tl) in enumerate(prompts_dev):
-      pre, _ = eng.prefill(params=params, padded_tokens=t, true_length=tl, slot=s)
-      prefixes.append(pre)
-    ds = eng.init_decode_state()
-    for s in range(B):
-      ds = eng.insert(prefixes[s], ds, s)
-    outs = []
-    for _ in range(args.decode_steps):
-      ds, res = eng.generate(params, ds)
-      if collect:
-        outs.append(res.data)
-    for s in range(B):
-      eng.release_pages(s)
-    return outs
-
-  def sync_all():
-    torch.cuda.synchronize()
-    if world > 1:
-      import torch.distributed as dist
-      dist.barrier()
-      torch.cuda.synchronize()
-
-  for _ in range(args.warmup):
-    one_pass()
-  sync_all()
-  t0 = time.perf_counter()
-  for _ in range(args.steps):
-    one_pass()
-  sync_all()
-  elapsed = time.perf_counter() - t0
-  if world > 1:
-    import torch.distributed as dist
-    te = torch.tensor([elapsed], dtype=torch.float64, device=device)
-    dist.all_reduce(te, op=dist.ReduceOp.MAX)
-    elapsed = float(te.item())
-
-  tokens_per_pass = B * (args.decode_steps + 1)
-  total_tokens = tokens_per_pass * args.steps * world
-  value = total_tokens / elapsed
-  nums = model_numbers(cfg)
-
-  # ---- separate timing of prefill-only and decode-only (rank 0 reporting detail)
-  detail = {}
-  if rank == 0:
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    prefixes = []
-    for s, (t, tl) in enumerate(prompts_dev):
-      pre, _ = eng.prefill(params=params, padded_tokens=t, true_length=tl, slot=s)
-      prefixes.append(pre)
-    torch.cuda.synchronize()
-    t_prefill = time.perf_counter() - t1
-    ds = eng.init_decode_state()
-    for s in range(B):
-      ds = eng.insert(prefixes[s], ds, s)
-    torch.cuda.synchronize()
-    t2 = time.perf_counter()
-    for _ in range(args.decode_steps):
-      ds, res = eng.generate(params, ds)
-    torch.cuda.synchronize()
-    t_decode = time.perf_counter() - t2
-    for s in range(B):
-      eng.release_pages(s)
-    ms_step = t_decode / args.decode_steps * 1e3
-    mean_ctx = P + args.decode_steps / 2.0
-    step_bytes = (nums["body_params"] + nums["unembed_params"]) * 2 + B * mean_ctx * nums["kv_bytes_per_token"] + B * nums["kv_bytes_per_token"]
-    step_flops = B * 2.0 * (nums["body_params"] + nums["unembed_params"]) + B * mean_ctx * nums["kv_bytes_per_token"]
-    detail = {
-        "prefill_ms_per_utterance": t_prefill / B * 1e3,
-        "decode_ms_per_step": ms_step,
-        "decode_tokens_per_s": B / (ms_step * 1e-3),
-        "decode_step_algorithmic_bytes": step_bytes,
-        "decode_hbm_frac": step_bytes / (ms_step * 1e-3) / HBM_PEAK,
-        "decode_mfu": step_flops / (ms_step * 1e-3) / MFMA_BF16_PEAK,
-    }
-
-  # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (eager launches of 16 decode steps).
-  # Two kernel families carry (almost) every HBM byte of a decode step: the one-launch decode attention (K/V pages) and the
-  # canonical dot (weights).  The one with the larger share of the step is reported; the other rides along in "other".
-  roofline = None
-  if rank == 0 and not args.no_roofline:
-    lib = eng.lib
-    import ctypes
-    prefixes = []
-    for s, (t, tl) in enumerate(prompts_dev):
-      pre, _ = eng.prefill(params=params, padded_tokens=t, true_length=tl, slot=s)
-      prefixes.append(pre)
-    ds = eng.init_decode_state()
-    for s in range(B):
-      ds = eng.insert(prefixes[s], ds, s)
-    # advance to the middle of the decode range (graph replay), so that the measured contexts are the average ones
-    mid = max(0, args.decode_steps // 2 - 8)
-    for _ in range(mid):
-      ds, res = eng.generate(params, ds)
-    torch.cuda.synchronize()
-    lib.ixt_timing_enable(eng._ctx, 1)
-    lib.ixt_timing_reset(eng._ctx)
-    nmeas = 16
-    for _ in range(nmeas):
-      ds, res = eng.generate(params, ds)
-
-    def fam(name):
-      avg_us, n, bpl = ctypes.c_double(), ctypes.c_int64(), ctypes.c_double()
-      lib.ixt_timing_get(eng._ctx, name, ctypes.byref(avg_us), ctypes.byref(n), ctypes.byref(bpl))
-      return avg_us.value, int(n.value), bpl.value
-    dot_us, dot_n, dot_bpl = fam(b"dot_decode")
-    att_us, att_n, _ = fam(b"attn_decode")
-    lib.ixt_timing_enable(eng._ctx, 0)
-    for s in range(B):
-      eng.release_pages(s)
-    # contexts during the measured steps: every utterance has true_length tl_s + mid + i + 1 keys at measured step i
-    ctx_sum = sum(tl + mid + (nmeas + 1) / 2.0 for (_, tl) in prompts)
-    kv_layer = nums["kv_bytes_per_token"] / cfg.num_decoder_layers                 # K+V bytes per token per layer (8 192 at C2)
-    att_bpl = ctx_sum * kv_layer + B * kv_layer                                    # read every cached key/value once + write the new one
-    traffic, traffic_src = None, None
-    for pmc in (os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"), os.path.join(ROOT, "profiles", f"r01_pmc_traffic_b{B}.json")):
-      if not os.path.exists(pmc):
-        continue
-      try:
-        pj = json.load(open(pmc))
-        if pj.get("batch") == B and pj.get("model") == args.model:
-          traffic, traffic_src = pj["hbm_bytes_per_launch"], pj.get("source")
-      except Exception:  # pylint: disable=broad-except
-        pass
-    dot = {"kernel": "k_gemm / k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
-           "achieved": dot_bpl / (dot_us * 1e-6) / 1e9 if dot_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": dot_us, "launches": dot_n,
-           "algorithmic_bytes_per_launch": dot_bpl, "us_per_step": dot_us * dot_n / nmeas}
-    att = {"kernel": "k_attn_decode (one launch per layer: QKV finalize, scores, softmax, PV over the paged KV cache)", "bound": "hbm",
-           "achieved": att_bpl / (att_us * 1e-6) / 1e9 if att_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": att_us, "launches": att_n,
-           "algorithmic_bytes_per_launch": att_bpl, "us_per_step": att_us * att_n / nmeas,
-           "mean_context": ctx_sum / B}
-    for d in (dot, att):
-      d["peak"] = HBM_PEAK / 1e9
-      d["frac"] = d["achieved"] / d["peak"]
-    main_k, other = (att, dot) if att["us_per_step"] >= dot["us_per_step"] else (dot, att)
-    roofline = dict(main_k)
-    roofline["traffic"] = traffic
-    roofline["traffic_source"] = traffic_src
-    roofline["other"] = other
-
-  # ---- CPU baseline: the oracle (a port restating the reference algorithm) on a bounded sample, rank 0, N=1 only
-  cpu_baseline = None
-  if rank == 0 and world == 1 and not args.no_cpu_baseline:
-    from oracle import oracle as O
-    O.lib().orc_set_num_threads(min(16, os.cpu_count() or 1))   # the GPU box's CPU share for one GPU
-    host_w = {k: v.detach().contiguous().view(torch.int16).cpu().numpy().view(np.uint16) for k, v in weights.items()}
-    ocfg = O.OracleConfig(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, num_query_heads=cfg.num_query_heads, num_kv_heads=cfg.num_kv_heads,
-                          head_dim=cfg.head_dim, mlp_dim=cfg.mlp_dim, num_decoder_layers=cfg.num_decoder_layers,
-                          normalization_layer_epsilon=cfg.normalization_layer_epsilon, max_target_length=T, max_prefill_predict_length=P,
-                          pagedattn_num_pages=pages_per_seq + 1, pagedattn_tokens_per_page=32, max_slots=1)
-    orc = O.OracleEngine(O.OracleModel(ocfg, host_w))
-    toks, tl = prompts[0]
-    c0 = time.perf_counter()
-    opre, ores = orc.prefill(toks, tl, slot=0)
-    c1 = time.perf_counter()
-    ods = orc.insert(opre, orc.init_decode_state(), 0)
-    otoks = [int(ores[0, 0])]
-    for _ in range(args.cpu_decode_steps):
-      ods, orr = orc.generate(ods)
-      otoks.append(int(orr[0, 0]))
-    c2 = time.perf_counter()
-    t_pre, t_step = c1 - c0, (c2 - c1) / max(1, args.cpu_decode_steps)
-    cpu_tps = (args.decode_steps + 1) / (t_pre + args.decode_steps * t_step)
-    # the same utterance on the GPU must give the same tokens (checker, not the thing measured)
-    pre, r0 = eng.prefill(params=params, padded_tokens=prompts_dev[0][0], true_length=tl, slot=0)
-    ds = eng.insert(pre, eng.init_decode_state(), 0)
-    gtoks = [int(r0.data[0, 0])]
-    for _ in range(args.cpu_decode_steps):
-      ds, r = eng.generate(params, ds)
-      gtoks.append(int(r.data[0, 0]))
-    eng.release_pages(0)
-    cpu_baseline = {"value": cpu_tps, "unit": "tokens/s", "cores": O.lib().orc_num_threads(), "kind": "port",
-                    "sample": f"oracle (C port of the reference algorithm; JAX unavailable): 1 utterance, {tl}-token prefill ({t_pre:.2f} s) + "
-                              f"{args.cpu_decode_steps} decode steps at ctx {tl}.. ({t_step:.3f} s/step), extrapolated to {args.decode_steps} steps at that step time",
-                    "host_cpus": os.cpu_count(), "tokens_match_gpu": otoks == gtoks}
-
-  if rank == 0:
-    out = {
-        "metric": "audio-tokens/sec (prefill+decode) @ 1B IndexTTS2", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16 (bf16 matrix-core dots, f32 accumulate; f32 fma chains in attention/norms)", "data": "synthetic",
-        "config": {"workload": f"C2 {args.model}: {P}-token prefill -> {args.decode_steps} greedy audio-token decode steps, {B} utterances/GPU, paged KV (32 tok/page)",
-                   "utterances_per_gpu": B, "prefill_len": P, "decode_steps": args.decode_steps, "parallelism": f"dp{world}", "hip_graph": not args.no_graph},
-        "per_gpu_tokens_per_s": value / world,
-        "detail": detail, "roofline": roofline, "cpu_baseline": cpu_baseline,
-    }
-    print(json.dumps(out), flush=True)
-  if world > 1:
-    import torch.distributed as dist
-    dist.barrier()
-    dist.destroy_process_group()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # Start the N rank processes from here, before anything has touched the GPU (a process that has initialised HIP must never
+    # be replaced or forked into ranks); the children are fresh interpreters running this file with the rank environment set.
+    dp_spawn = importlib.import_module("maxtext-indextts2_amd.dp_spawn")
+    sys.exit(dp_spawn.spawn_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
+  run_rank(args)
 
 
 if __name__ == "__main__":

@@ -43,6 +43,30 @@ def barrier():
     dist.barrier()
 
 
+def timed_region(one_pass, steps: int, warmup: int, sync_device, device: torch.device | None = None) -> float:
+  """The bench contract: `warmup` untimed passes, then exactly `steps` passes bracketed by barrier + device synchronise on both
+  sides; returns the MAX over ranks of the elapsed seconds.  `sync_device` = torch.cuda.synchronize (or a no-op on CPU)."""
+  import time  # pylint: disable=import-outside-toplevel
+  for _ in range(warmup):
+    one_pass()
+  sync_device()
+  barrier()
+  sync_device()
+  t0 = time.perf_counter()
+  for _ in range(steps):
+    one_pass()
+  sync_device()
+  barrier()
+  sync_device()
+  return max_over_ranks(time.perf_counter() - t0, device)
+
+
+def finish():
+  if dist.is_initialized():
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def gather_token_ids(local_ids: Sequence[int], local_tokens: torch.Tensor, n_total: int) -> torch.Tensor | None:
   """local_tokens int32 [len(local_ids), T] -> on rank 0 an int32 [n_total, T] matrix in global utterance order."""
   if not dist.is_initialized() or dist.get_world_size() == 1:
