@@ -276,6 +276,36 @@ def audio_id_to_embedding_row(a: int) -> int:
   return 6 + a if a < 99 else 256001 + (a - 99)
 
 
+# ----------------------------------------------------------------------------- attention masks (boolean, exact)
+def reference_prefill_mask(q_len: int, kv_len: int, next_pos: int = 0, q_segment_ids=None, kv_segment_ids=None) -> np.ndarray:
+  """attentions.py:586-618 (`generate_attention_mask`, prefill / train mode, global attention): segment equality AND the SARATHI causal
+  rule `col <= row + next_pos` (next_pos = length of the previous chunks).  Returns bool [q_len, kv_len], True = attend."""
+  row = np.arange(q_len, dtype=np.int32)[:, None]
+  col = np.arange(kv_len, dtype=np.int32)[None, :]
+  m = col <= row + next_pos
+  if q_segment_ids is not None:
+    m = m & (np.asarray(q_segment_ids)[:, None] == np.asarray(kv_segment_ids)[None, :])
+  return m
+
+
+def ragged_paged_mask(q_len: int, kv_len: int) -> np.ndarray:
+  """paged_attention_kernel_v2.py:100-103 (`ref_ragged_paged_attention`): masked where (kv_len - q_len) + row < col."""
+  row = np.arange(q_len, dtype=np.int32)[:, None]
+  col = np.arange(kv_len, dtype=np.int32)[None, :]
+  return ~((kv_len - q_len) + row < col)
+
+
+def row_visibility(row_slot, row_pos, n_keys: int) -> np.ndarray:
+  """What THIS build's row descriptors express: row r (slot s_r, position p_r) attends to positions [0, p_r] of slot s_r.
+  Returns bool [R, nslots, n_keys]."""
+  row_slot, row_pos = np.asarray(row_slot), np.asarray(row_pos)
+  nslots = int(row_slot.max()) + 1
+  vis = np.zeros((len(row_slot), nslots, n_keys), bool)
+  for r, (s, p) in enumerate(zip(row_slot, row_pos)):
+    vis[r, s, :p + 1] = True
+  return vis
+
+
 # ----------------------------------------------------------------------------- model
 @dataclass
 class OracleConfig:

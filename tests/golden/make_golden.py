@@ -3,6 +3,7 @@
 
   audio_token_mapping_adjusted.npz   the reference's audio-id <-> embedding-row table (data file
                                      /root/reference/audio_token_mapping_adjusted.json) in array form
+  audio_token_mappings_other.npz     its two other mapping files (vocab_expansion/audio_token_mapping{,_complete}.json) in array form
   tiny_decode.npz / c1_decode.npz / c2_decode.npz
                                      greedy token ids produced by the CPU ORACLE (oracle/ixt_oracle.c) on seeded synthetic
                                      weights and prompts.  These pin the oracle against drift and give the GPU tests a
@@ -40,6 +41,38 @@ def mapping():
   np.savez_compressed(os.path.join(HERE, "audio_token_mapping_adjusted.npz"), audio_to_embedding=a2e, embedding_rows=rows, embedding_audio_id=aud,
                       stats=np.array(json.dumps(d["stats"])), sha256=np.array(hashlib.sha256(raw).hexdigest()))
   print("mapping:", d["stats"], hashlib.sha256(raw).hexdigest()[:8])
+
+
+def mappings_other():
+  """The reference's two other mapping data files in array form, with their sha256: vocab_expansion/audio_token_mapping.json
+  (tokenizer index -> audio id, before the soft-token shift) and vocab_expansion/audio_token_mapping_complete.json."""
+  out = {}
+  src = "/root/reference/vocab_expansion/audio_token_mapping.json"
+  raw = open(src, "rb").read()
+  d = json.loads(raw)
+  idx = np.array(sorted(int(k) for k in d["audio_mappings"]), np.int32)
+  out["simple_tokenizer_index"] = idx
+  out["simple_audio_id"] = np.array([int(d["audio_mappings"][str(i)]) for i in idx], np.int32)
+  out["simple_vocab_size"] = np.array(int(d["vocab_size"]))
+  out["simple_sha256"] = np.array(hashlib.sha256(raw).hexdigest())
+  src = "/root/reference/vocab_expansion/audio_token_mapping_complete.json"
+  raw = open(src, "rb").read()
+  d = json.loads(raw)
+  rows = np.array(sorted(int(k) for k in d["embedding_to_audio"]), np.int32)
+  out["complete_embedding_rows"] = rows
+  out["complete_embedding_audio_id"] = np.array([int(d["embedding_to_audio"][str(r)]) for r in rows], np.int32)
+  a2e = np.full((8192,), -1, np.int32)
+  for k, v in d["audio_to_embedding"].items():
+    a2e[int(k)] = int(v)
+  out["complete_audio_to_embedding"] = a2e
+  tix = np.array(sorted(int(k) for k in d["tokenizer_to_audio"]), np.int32)
+  out["complete_tokenizer_index"] = tix
+  out["complete_tokenizer_audio_id"] = np.array([int(d["tokenizer_to_audio"][str(t)]) for t in tix], np.int32)
+  out["complete_detail_original_token_idx"] = np.array([int(d["detailed_mappings"][str(r)]["original_token_idx"]) for r in rows], np.int32)
+  out["complete_stats"] = np.array(json.dumps(d["stats"]))
+  out["complete_sha256"] = np.array(hashlib.sha256(raw).hexdigest())
+  np.savez_compressed(os.path.join(HERE, "audio_token_mappings_other.npz"), **out)
+  print("mappings_other:", out["simple_sha256"].item()[:8], out["complete_sha256"].item()[:8], d["stats"])
 
 
 def decode_fixture(name, cfg, seed_w, prompts, steps, B):
@@ -147,4 +180,4 @@ def c2_rows_256():
 if __name__ == "__main__":
   which = sys.argv[1:] or ["mapping", "tiny", "c1"]
   for w in which:
-    {"mapping": mapping, "tiny": tiny, "c1": c1, "c2": c2, "c2_rows_130": c2_rows_130, "c2_rows_256": c2_rows_256}[w]()
+    {"mapping": mapping, "mappings_other": mappings_other, "tiny": tiny, "c1": c1, "c2": c2, "c2_rows_130": c2_rows_130, "c2_rows_256": c2_rows_256}[w]()

@@ -112,3 +112,27 @@ def test_oracle_sampling_ranges():
     allowed[lo:hi] = True
   assert lim[0] == int(np.flatnonzero(allowed)[np.argmax(row[allowed])]) and free[0] == int(np.argmax(row))
   assert not np.array_equal(free, lim)
+
+
+def test_other_reference_mapping_files_agree(mapping):
+  """The reference ships three mapping data files; the adjusted one drives this build.  The other two
+  (vocab_expansion/audio_token_mapping.json, sha256 abf2cbca..., and audio_token_mapping_complete.json, sha256 6644cd61...) are pinned
+  here in array form and must tell the same story: same audio-id -> embedding-row table, and tokenizer indices that differ from
+  embedding rows by exactly the removed soft token at 262144 (extend_tokenizer.py:40-46)."""
+  g = np.load(os.path.join(H.GOLDEN, "audio_token_mappings_other.npz"))
+  assert str(g["simple_sha256"]).startswith("abf2cbca") and str(g["complete_sha256"]).startswith("6644cd61")
+  # complete file: the embedding-side tables are the adjusted file's tables
+  assert np.array_equal(g["complete_audio_to_embedding"], mapping.audio_to_embedding)
+  assert np.array_equal(g["complete_embedding_rows"], mapping.embedding_rows)
+  assert np.array_equal(g["complete_embedding_audio_id"], mapping.embedding_audio_id)
+  # tokenizer index -> embedding row: indices above the soft token (262144) shift down by one, the soft token itself never appears
+  for tix, aid in ((g["simple_tokenizer_index"], g["simple_audio_id"]), (g["complete_tokenizer_index"], g["complete_tokenizer_audio_id"])):
+    assert 262144 not in set(tix.tolist())
+    rows = np.where(tix > 262144, tix - 1, tix)
+    assert np.array_equal(rows, mapping.embedding_rows) and np.array_equal(aid, mapping.embedding_audio_id)
+  assert np.array_equal(np.where(g["complete_detail_original_token_idx"] > 262144, g["complete_detail_original_token_idx"] - 1,
+                                 g["complete_detail_original_token_idx"]), mapping.embedding_rows)
+  assert int(g["simple_vocab_size"]) == 264193            # tokenizer size; the embedding table has one row less (264192)
+  import json
+  st = json.loads(str(g["complete_stats"]))
+  assert st["adjusted_embedding_size"] == 264192 and st["total_audio_tokens"] == 8192 and st["padding_added"] == 98
