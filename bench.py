@@ -57,6 +57,7 @@ def parse(argv=None):
   ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (the GPU box's CPU share for one GPU is 16)")
   ap.add_argument("--sync-every", type=int, default=0, help="synchronise the stream every N engine calls (profiling runs: bounds the launch backlog)")
   ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU rehearsal)")
+  ap.add_argument("--opt", action="append", default=[], help="library option name=value (ixt_set_option), e.g. kv_head_major=1; experiments")
   ap.add_argument("--stub-engine", action="store_true", help="CPU rehearsal of the multi-process plumbing (tests/test_dp_cpu.py): no GPU, no model")
   return ap.parse_args(argv)
 
@@ -204,6 +205,10 @@ def make_engine(args, pyconfig, maxengine, B, device_weights=None):
       pagedattn_num_pages=(B + (pack if pack > 1 else 0)) * pages_per_seq + 1, ixt_use_hip_graph=not args.no_graph, run_name="bench",
       ixt_staging_groups=pack if pack > 1 else 0, ixt_max_packed_rows=pack * P if pack > 1 else 0)
   eng = maxengine.MaxEngine(cfg)
+  lib = importlib.import_module("maxtext-indextts2_amd._lib")
+  for kv in args.opt:
+    k, v = kv.split("=")
+    lib.check(eng.lib.ixt_set_option(eng._ctx, k.encode(), int(v)))
   return cfg, eng, pack
 
 

@@ -152,6 +152,10 @@ int ixt_op_rmsnorm(ixt_ctx* ctx, const uint16_t* x, const uint16_t* scale, uint1
 int ixt_op_rope(ixt_ctx* ctx, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream);
 /* MlpBlock gate (linears.py:459-464): out = bf16(bf16(silu(a)) * b), n elements. */
 int ixt_op_swiglu(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+/* Residual add of the decoder block (llama2.py:127, :157): out = bf16(a + b), n elements. */
+int ixt_op_residual(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+/* Embed.__call__ (embeddings.py:131-163): out bf16[R][E] = table bf16[V][E] rows ids[R] (ids clamped to the table, as a jnp gather is). */
+int ixt_op_embed(ixt_ctx* ctx, const uint16_t* table, const int32_t* ids, uint16_t* out, int R, int E, int V, void* stream);
 /* PagedAttentionOp page writes (paged_attention.py:403-471): k,v bf16[R][nkv][hd] (post-RoPE) into `layer`'s
  * pages of row_slot[r] at row_pos[r] (rows with row_active[r]==0 skipped). */
 int ixt_op_kv_write(ixt_ctx* ctx, int layer, const uint16_t* k, const uint16_t* v, const int32_t* row_slot,

@@ -61,6 +61,8 @@ SIGNATURES = {
     "ixt_op_rmsnorm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_rope": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_swiglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
+    "ixt_op_residual": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
+    "ixt_op_embed": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_kv_write": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp]),
     "ixt_op_paged_attention": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
     "ixt_op_unembed_argmax": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),

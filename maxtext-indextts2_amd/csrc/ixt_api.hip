@@ -1154,6 +1154,20 @@ extern "C" int ixt_op_swiglu(ixt_ctx* c, const uint16_t* a, const uint16_t* b, u
   return IXT_OK;
 }
 
+extern "C" int ixt_op_residual(ixt_ctx* c, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
+  if (!c || !a || !b || !out || n <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_residual, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_embed(ixt_ctx* c, const uint16_t* table, const int32_t* ids, uint16_t* out, int R, int E, int V, void* stream) {
+  if (!c || !table || !ids || !out || R <= 0 || E <= 0 || E % 8 || V <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_embed, dim3((E / 8 + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, table, ids, out, E, V);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
 extern "C" int ixt_op_kv_write(ixt_ctx* c, int layer, const uint16_t* k, const uint16_t* v, const int32_t* row_slot, const int32_t* row_pos,
                                const int32_t* row_active, int R, void* stream) {
   if (!c || !k || !v || layer < 0 || layer >= c->L || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");

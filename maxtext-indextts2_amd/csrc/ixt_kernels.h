@@ -683,6 +683,20 @@ __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slic
   *reinterpret_cast<u32x4*>(out + xidx(r, f0, F)) = ov;
 }
 
+// op-level helpers of the layers.* module surface: residual add bf16(a + b) (llama2.py:127, :157) and the embedding gather
+// (embeddings.py:154).  Elementwise, 8 elements per thread where the size allows.
+__global__ __launch_bounds__(256) void k_residual(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = f2bf(bf2f(a[i]) + bf2f(b[i]));
+}
+__global__ __launch_bounds__(256) void k_embed(const bf16_t* table, const int32_t* ids, bf16_t* out, int E, int V) {
+  const int r = blockIdx.y, c = (blockIdx.x * 256 + threadIdx.x) * 8;
+  if (c >= E) return;
+  int id = ids[r];
+  id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+  *reinterpret_cast<u32x4*>(out + (size_t)r * E + c) = *reinterpret_cast<const u32x4*>(table + (size_t)id * E + c);
+}
+
 __global__ __launch_bounds__(256) void k_swiglu(const bf16_t* a, const bf16_t* b, bf16_t* out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = ixt_swiglu(bf2f(a[i]), bf2f(b[i]));
