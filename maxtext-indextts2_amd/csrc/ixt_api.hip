@@ -1283,3 +1283,6 @@ extern "C" int ixt_timing_get(ixt_ctx* c, const char* family, double* avg_us, in
   if (bytes_per_launch) *bytes_per_launch = tot_bytes / n;
   return IXT_OK;
 }
+
+// the training step (include/ixt_train.h) shares this translation unit: the kernels of ixt_kernels.h are defined once
+#include "ixt_train.hip"

@@ -61,6 +61,29 @@ def timed_region(one_pass, steps: int, warmup: int, sync_device, device: torch.d
   return max_over_ranks(time.perf_counter() - t0, device)
 
 
+def exchange_gradients(grads: torch.Tensor, loss_and_weights: torch.Tensor, algorithm: str = "auto", bucket_elems: int = 64 << 20) -> None:
+  """The data-parallel step of train_step: every rank ends with the SUM over ranks of the flat gradient buffer and of
+  [total_loss, total_weights] (GSPMD emits this all-reduce implicitly in the reference; loss = sum / sum as in
+  train.py:307-322).  In place.  algorithm "rs_ag" (what "auto" picks): per bucket a reduce-scatter followed by an all-gather -- on the
+  8 fully connected GPUs of a node every rank exchanges 1/8 of the bucket with each of its 7 peers at once, all xGMI links busy, where a
+  ring all-reduce is bound by one link; "all_reduce": one all-reduce per bucket."""
+  if not dist.is_initialized() or dist.get_world_size() == 1:
+    return
+  world = dist.get_world_size()
+  dist.all_reduce(loss_and_weights, op=dist.ReduceOp.SUM)
+  algo = "rs_ag" if algorithm == "auto" else algorithm
+  n = grads.numel()
+  step = max(world, (bucket_elems // world) * world)
+  for b0 in range(0, n, step):
+    bucket = grads[b0:min(n, b0 + step)]
+    if algo == "all_reduce" or bucket.numel() % world:      # a ragged tail bucket: plain all-reduce
+      dist.all_reduce(bucket, op=dist.ReduceOp.SUM)
+      continue
+    shard = torch.empty((bucket.numel() // world,), dtype=bucket.dtype, device=bucket.device)
+    dist.reduce_scatter_tensor(shard, bucket, op=dist.ReduceOp.SUM)
+    dist.all_gather_into_tensor(bucket, shard)
+
+
 def finish():
   if dist.is_initialized():
     dist.barrier()
