@@ -57,13 +57,21 @@ def test_train_steps_match_oracle(shape):
   orc = TO.TrainOracle(cfg, params)
   batches = [AT.synthetic_batch(cfg, 10), packed_batch(cfg, 11), AT.synthetic_batch(cfg, 12), packed_batch(cfg, 13)]
   for step, b in enumerate(batches):
+    # identical state going into the step: parameters and AdamW moments of the oracle (Adam turns gradient noise at the 1e-3 level into
+    # update differences at the level of lr, so free-running trajectories part at 1e-4..1e-3 in the loss after a few steps: second test)
+    trainer.load_params({k: v.detach().numpy() for k, v in orc.p.items()})
+    for buf, src in ((trainer.mu, orc.mu), (trainer.nu, orc.nu)):
+      for k, v in trainer.param_views(buf).items():
+        v.copy_(src[k])
+    trainer.step = orc.step
+    before = {k: v.detach().clone() for k, v in orc.p.items()}
     m = trainer.train_step(b)
-    # gradients of this step, before the oracle moves its parameters
     g_hip = {k: v.clone() for k, v in trainer.param_views(trainer.grads).items()}
     o = orc.train_step(b)
     assert m["learning/total_weights"] == o["learning/total_weights"]
     assert abs(m["learning/loss"] - o["learning/loss"]) <= 1e-4 * abs(o["learning/loss"]), (step, m["learning/loss"], o["learning/loss"])
     assert abs(m["learning/raw_grad_norm"] - o["learning/raw_grad_norm"]) <= 3e-3 * o["learning/raw_grad_norm"], (step, m, o["learning/raw_grad_norm"])
+    assert abs(m["learning/grad_norm"] - o["learning/grad_norm"]) <= 3e-3 * o["learning/grad_norm"]
     assert abs(m["learning/current_learning_rate"] - o["learning/current_learning_rate"]) < 1e-12
     denom = o["learning/total_weights"] + 1e-8
     for k, g in g_hip.items():
@@ -71,10 +79,34 @@ def test_train_steps_match_oracle(shape):
       got = g.cpu() / denom                           # the buffer holds the gradient of total_loss (train.py:307-322)
       err = float((got - ref).norm()) / (float(ref.norm()) + 1e-12)
       assert err < 2e-2, (step, k, err)
-  # parameters after four AdamW steps
-  for k, v in trainer.param_views().items():
-    ref = orc.p[k].detach()
-    assert float((v.cpu() - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-6, k
+    # the AdamW update of this step: same direction and size as the oracle's, tensor by tensor
+    if o["learning/current_learning_rate"] > 0:
+      for k, v in trainer.param_views().items():
+        d_hip, d_ref = v.cpu() - before[k], orc.p[k].detach() - before[k]
+        if float(d_ref.norm()) > 0:
+          cos = float((d_hip * d_ref).sum()) / (float(d_hip.norm()) * float(d_ref.norm()) + 1e-30)
+          assert cos > 0.98 and abs(float(d_hip.norm()) / float(d_ref.norm()) - 1) < 2e-2, (step, k, cos)
+  del trainer
+  torch.cuda.synchronize()
+
+
+def test_free_running_trajectory_stays_close():
+  """Six steps on a repeated batch without re-synchronising (the loss falls five-fold): the trajectory stays within 1 % of the oracle's
+  (Adam amplifies the bf16 noise of the product's backward signals: the per-step bar with identical state is the 1e-4 of the test above)."""
+  import torch
+  tr = importlib.import_module("maxtext-indextts2_amd.train")
+  cfg = train_config(learning_rate=5e-3, warmup_steps_fraction=0.1)
+  params = f32_params(cfg, 5)
+  trainer = tr.Trainer(cfg)
+  trainer.load_params(params)
+  orc = TO.TrainOracle(cfg, params)
+  b = packed_batch(cfg, 21)
+  losses = []
+  for step in range(6):
+    m, o = trainer.train_step(b), orc.train_step(b)
+    assert abs(m["learning/loss"] - o["learning/loss"]) <= 1e-2 * abs(o["learning/loss"]), (step, m["learning/loss"], o["learning/loss"])
+    losses.append(m["learning/loss"])
+  assert losses[-1] < losses[1] < losses[0] + 1e-6
   del trainer
   torch.cuda.synchronize()
 
