@@ -2,7 +2,7 @@
 // llama2 block stack, cross entropy with its custom VJP (max_utils.py:563-654), global-norm clip (maxtext_utils.py:825-846) and AdamW
 // (optimizers.py:28-38).  Precision: bf16 activations and matmul operands, f32 accumulation (v_mfma_f32_16x16x32_bf16), f32 master
 // weights / gradients / optimizer state -- the reference's dtype=bfloat16, weight_dtype=float32 (base.yml:86, :130).
-// The tolerance of this path is 1e-4 relative on the loss against the f32 PyTorch restatement (oracle/train_oracle.py); it is NOT the
+// The tolerance of this path is 1e-4 relative on the loss against the f32 PyTorch restatement the tests hold (tests/test_gpu_train.py); it is NOT the
 // bit-exact contract of the decode path, so reductions here use whatever order is fastest unless stated.
 #pragma once
 #include "ixt_device.h"

@@ -211,6 +211,13 @@ def test_abi_exports_every_declared_symbol():
   assert lib.ixt_create(None, None) == H.lib.IXT_ERR_INVALID
   with pytest.raises(ValueError):
     H.lib.check(lib.ixt_create(None, None))
+  # the training-step ABI (include/ixt_train.h) lives in the same library
+  thdr = open(os.path.join(H.ROOT, "include", "ixt_train.h")).read()
+  tdeclared = set(re.findall(r"\b(ixt_train_[a-z0-9_]+)\s*\(", thdr))
+  assert len(tdeclared) >= 10
+  for name in tdeclared:
+    assert hasattr(lib, name), name
+  assert lib.ixt_train_create(None, None) == H.lib.IXT_ERR_INVALID
 
 
 def test_product_has_no_cpu_fallback_and_no_oracle_import():
