@@ -206,6 +206,7 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "ring_cfg"               0 (default): tile chosen per shape; 1: 128 x 128, 2: 128 rows x 64 columns, 3: 64 x 32
  *   "ring_split"             1: ixt_op_dot's ring GEMM runs split over the 512-k chains (one f32 slice per chain)
  *   "ring_wlayout"           1: ixt_op_dot stores its weights in the ring layout ([n/128][k/64][16 fragments]: one sequential stream per block)
+ *   "unembed_tall"           1 (default): the unembedding at 129..256 rows uses 256 x 128 tiles (weights enter the chip once); 0: 128 x 128
  *   "ring_down"              MLP down-projection on the ring path: 1 ring GEMM + residual epilogue, 0 split-K tiles + slice-sum kernel,
  *                            -1 (default) by shape */
 int ixt_set_option(ixt_ctx* ctx, const char* name, int value);

@@ -88,6 +88,7 @@ struct ixt_ctx {
   // MLP down-projection on the ring path: 1 = ring GEMM with the residual epilogue; 0 = split-K tiles (one f32 slice per 512-k chain, two blocks
   // per CU) + slice-sum / residual / norm kernel; -1 (default) = by shape: the ring form needs at least 192 whole-K blocks of 128 x 128 or 128 x 64
   int ring_down = -1;
+  int unembed_tall = 1;   // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -547,7 +548,12 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   else if (epi == GEPI_F32) RING(GEPI_F32);
   else if (epi == GEPI_RESID) RING(GEPI_RESID);
   else if (epi == GEPI_QKV) RING(GEPI_QKV);
-  else if (epi == GEPI_UNEMBED) rc = RING_A(GEPI_UNEMBED, 0);
+  else if (epi == GEPI_UNEMBED) {
+    // the unembedding at 129..256 rows: ONE block owns all rows of its 128 columns (8 waves of 64 x 64: 256 x 128 tile, 3 slots of 48 KiB), so the
+    // 1 GB kernel enters the chip once instead of once per 128-row group
+    if (c->unembed_tall && R > 128 && R <= 256) rc = ring_launch_t<4, 2, 4, 4, 2, 3, GEPI_UNEMBED, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);
+    else rc = RING_A(GEPI_UNEMBED, 0);
+  }
   else if (epi == GEPI_SWIGLU) {
     if (cfg == 1) rc = RING_A(GEPI_SWIGLU, 0);
     else rc = ring_launch_t<2, 2, 4, 2, 2, 5, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);   // gate pairs need two tiles per wave: 4 waves
@@ -1235,7 +1241,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
-      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1},
+      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

@@ -12,8 +12,8 @@ typedef short tbf16x8 __attribute__((ext_vector_type(8)));
 
 // ---------------------------------------------------------------------------------------------------------------- general GEMM
 // C[m][n] (+)= sum_k A(m, k) B(k, n) for bf16 operands with arbitrary element strides (either index may be the contiguous one), f32
-// accumulation, two-level batch (z = z1 * nb2 + z2).  Block = 128 x 128 x 32, 4 waves as 2 x 2, wave = 64 x 64 = 4 x 4 MFMA tiles.
-// Both operand tiles go through LDS as [row][k] with k contiguous (rows padded to 40 elements: 16-byte aligned fragment reads,
+// accumulation, two-level batch (z = z1 * nb2 + z2).  Block = 128 x 128 x 64, 4 waves as 2 x 2, wave = 64 x 64 = 4 x 4 MFMA tiles.
+// Both operand tiles go through LDS as [row][k] with k contiguous (rows padded to 72 elements: 16-byte aligned fragment reads,
 // conflict-light); a tile whose memory-contiguous index is not k is transposed on its way in (8 two-byte LDS stores per 16-byte load).
 // MFMA roles: A-operand = B tile rows (n), B-operand = A tile rows (m), so a lane ends with 4 consecutive n of one m.
 struct TGemm {
@@ -25,25 +25,33 @@ struct TGemm {
   int accumulate;                     // f32 output only: C += result
 };
 
-#define TG_LD 40
-__device__ __forceinline__ void tg_load_tile(bf16_t* __restrict__ lds, const bf16_t* __restrict__ g, long s_row, long s_k, int row0, int k0, int nrows, int K,
-                                             int tid) {
-  // tile = 128 rows x 32 k.  512 vectors of 8 elements, 2 per thread.
-  if (s_k == 1) {
+#define TG_LD 72     // LDS row pitch in elements: 64 k + 8 (16-byte aligned fragment reads, rows spread over the banks)
+#define TG_BK 64
+// One operand tile = 128 rows x 64 k = 1024 vectors of 8 elements, 4 per thread: fetched into registers (tg_fetch) while the previous
+// tile is being multiplied, written to LDS afterwards (tg_store) -- the global latency runs under the MFMAs.
+__device__ __forceinline__ void tg_fetch(u32x4 (&r)[4], const bf16_t* __restrict__ g, long s_row, long s_k, int row0, int k0, int nrows, int K, int tid) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int v = tid + it * 256, r = v >> 2, kk = (v & 3) * 8;
-      u32x4 val = u32x4(0);
-      if (row0 + r < nrows && k0 + kk < K) val = *reinterpret_cast<const u32x4*>(g + (long)(row0 + r) * s_row + (k0 + kk));
-      *reinterpret_cast<u32x4*>(lds + r * TG_LD + kk) = val;
+  for (int it = 0; it < 4; ++it) {
+    const int v = tid + it * 256;
+    r[it] = u32x4(0);
+    if (s_k == 1) {
+      const int rr = v >> 3, kk = (v & 7) * 8;
+      if (row0 + rr < nrows && k0 + kk < K) r[it] = *reinterpret_cast<const u32x4*>(g + (long)(row0 + rr) * s_row + (k0 + kk));
+    } else {   // rows are the contiguous index (s_row == 1): 8 consecutive rows at one k per load
+      const int rr = (v & 15) * 8, kk = v >> 4;
+      if (row0 + rr < nrows && k0 + kk < K) r[it] = *reinterpret_cast<const u32x4*>(g + (long)(k0 + kk) * s_k + (row0 + rr));
     }
-  } else {   // rows are the contiguous index (s_row == 1): 8 consecutive rows at one k per load
+  }
+}
+__device__ __forceinline__ void tg_store(bf16_t* __restrict__ lds, const u32x4 (&r)[4], long s_k, int tid) {
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
-      const int v = tid + it * 256, rr = (v & 15) * 8, kk = v >> 4;
-      u32x4 val = u32x4(0);
-      if (row0 + rr < nrows && k0 + kk < K) val = *reinterpret_cast<const u32x4*>(g + (long)(k0 + kk) * s_k + (row0 + rr));
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&val);
+  for (int it = 0; it < 4; ++it) {
+    const int v = tid + it * 256;
+    if (s_k == 1) {
+      *reinterpret_cast<u32x4*>(lds + (v >> 3) * TG_LD + (v & 7) * 8) = r[it];
+    } else {
+      const int rr = (v & 15) * 8, kk = v >> 4;
+      const bf16_t* e = reinterpret_cast<const bf16_t*>(&r[it]);
 #pragma unroll
       for (int j = 0; j < 8; ++j) lds[(rr + j) * TG_LD + kk] = e[j];
     }
@@ -65,19 +73,29 @@ __global__ __launch_bounds__(256) void k_tgemm(TGemm g) {
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = tf32x4(0.0f);
-  for (int k0 = 0; k0 < g.K; k0 += 32) {
-    tg_load_tile(As, A, g.sam, g.sak, m0, k0, g.M, g.K, tid);
-    tg_load_tile(Bs, B, g.sbn, g.sbk, n0, k0, g.N, g.K, tid);
+  u32x4 ra[4], rbv[4];
+  tg_fetch(ra, A, g.sam, g.sak, m0, 0, g.M, g.K, tid);
+  tg_fetch(rbv, B, g.sbn, g.sbk, n0, 0, g.N, g.K, tid);
+  for (int k0 = 0; k0 < g.K; k0 += TG_BK) {
+    tg_store(As, ra, g.sak, tid);
+    tg_store(Bs, rbv, g.sbk, tid);
     __syncthreads();
-    tbf16x8 af[4], bf[4];
+    if (k0 + TG_BK < g.K) {                       // the next tile's loads fly while this one is multiplied
+      tg_fetch(ra, A, g.sam, g.sak, m0, k0 + TG_BK, g.M, g.K, tid);
+      tg_fetch(rbv, B, g.sbn, g.sbk, n0, k0 + TG_BK, g.N, g.K, tid);
+    }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const tbf16x8*>(As + (wr * 64 + i * 16 + r_in) * TG_LD + q * 8);
+    for (int ks = 0; ks < 2; ++ks) {
+      tbf16x8 af[4], bf[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const tbf16x8*>(Bs + (wc * 64 + j * 16 + r_in) * TG_LD + q * 8);
+      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const tbf16x8*>(As + (wr * 64 + i * 16 + r_in) * TG_LD + ks * 32 + q * 8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const tbf16x8*>(Bs + (wc * 64 + j * 16 + r_in) * TG_LD + ks * 32 + q * 8);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], af[i], acc[i][j], 0, 0, 0);
+    }
     __syncthreads();
   }
   // D[i = n row][j = m col]: lane holds m = .. + r_in, n = .. + q * 4 + reg
