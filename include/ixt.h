@@ -104,7 +104,8 @@ int ixt_pages_move(ixt_ctx* ctx, int src_group, int dst_slot, void* stream);
  * `length` tokens for dst_slot, then copy the K and V pages of src_group, all layers.  src_group stays valid. */
 int ixt_pages_copy(ixt_ctx* ctx, int src_group, int dst_slot, int length, void* stream);
 /* Page-pool shortage is silent in the reference (page_manager.py:305-311).  out4 (HOST) = {reservations that found no room since the
- * last reset, the last group that failed, decode rows left without a page, 0}; synchronises `stream`; reset != 0 clears the counters. */
+ * last reset, the last group that failed, decode rows left without a page, packed prefill rows at or beyond their call's max_len};
+ * synchronises `stream`; reset != 0 clears the counters. */
 int ixt_pages_status(ixt_ctx* ctx, int32_t* out4, int reset, void* stream);
 /* Copy the seven PageState fields to HOST arrays (synchronises `stream`); the decode slots' groups only:
  * page_status[num_pages], page_map[max_slots*max_pages_per_group], num_pages_used[max_slots],
@@ -126,8 +127,10 @@ int ixt_prefill_chunk(ixt_ctx* ctx, int slot, const int32_t* tokens_dev, int n_t
 /* MaxEngine.prefill_concat's model pass (maxengine.py:719-836) over pages: n_rows rows of several prompts as one ragged batch -- row i =
  * token tokens_dev[i] at position row_pos_dev[i] of page group row_group_dev[i] (pages already reserved; decode slots or staging groups);
  * rows of different groups never see each other.  first_tokens_dev[j] = argmax of the logits of row logits_rows_dev[j] (the last row of
- * prompt j, :797-812), logits_dev f32[n_logits][vocab] may be NULL.  All arrays are device arrays. */
-int ixt_prefill_rows(ixt_ctx* ctx, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev,
+ * prompt j, :797-812), logits_dev f32[n_logits][vocab] may be NULL.  All arrays are device arrays.  max_len: the caller's bound on
+ * position + 1 over the rows (the longest prompt end; it sizes the on-chip score rows of the tiled attention; <= 0: max_target_length);
+ * a row at or beyond it is left idle and counted in ixt_pages_status()[3]. */
+int ixt_prefill_rows(ixt_ctx* ctx, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev, int max_len,
                      int n_logits, const int32_t* logits_rows_dev, int32_t* first_tokens_dev, float* logits_dev, void* stream);
 /* MaxEngine._generate_jit model step (maxengine.py:868-936) for all slots: row b = token tokens_dev[b] at
  * position pos_dev[b]; rows without an active page, outside max_target_length or beyond the pages granted to the slot write no K/V
@@ -206,6 +209,8 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "ring_cfg"               0 (default): tile chosen per shape; 1: 128 x 128, 2: 128 rows x 64 columns, 3: 64 x 32
  *   "ring_split"             1: ixt_op_dot's ring GEMM runs split over the 512-k chains (one f32 slice per chain)
  *   "ring_wlayout"           1: ixt_op_dot stores its weights in the ring layout ([n/128][k/64][16 fragments]: one sequential stream per block)
+ *   "attn_tile"              1 (default): prefill calls of at least "attn_tile_min_rows" rows (default 64) run the tiled attention: 16 (8 past
+ *                            ~1500 keys) consecutive rows per block share every K / V load; 0: one block per (row, kv head) as for decode rows
  *   "unembed_tall"           1 (default): the unembedding at 129..256 rows uses 256 x 128 tiles (weights enter the chip once); 0: 128 x 128
  *   "ring_down"              MLP down-projection on the ring path: 1 ring GEMM + residual epilogue, 0 split-K tiles + slice-sum kernel,
  *                            -1 (default) by shape */

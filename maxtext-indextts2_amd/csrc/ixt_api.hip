@@ -89,6 +89,8 @@ struct ixt_ctx {
   // per CU) + slice-sum / residual / norm kernel; -1 (default) = by shape: the ring form needs at least 192 whole-K blocks of 128 x 128 or 128 x 64
   int ring_down = -1;
   int unembed_tall = 1;   // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
+  int attn_tile = 1;         // prefill rows: tiled attention (k_attn_tile) from attn_tile_min_rows rows on
+  int attn_tile_min_rows = 64;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -863,6 +865,43 @@ static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr
   else hipLaunchKernelGGL((k_attn_decode<HD, GQ, false>), dim3(g.nkv, R), dim3(256), lds, st, da);
 }
 
+// prefill rows (q in qbuf, K/V already in the pages): NQ query vectors per block share every K / V load.  false: the score rows of
+// len_hint keys do not fit the LDS (the caller takes the per-row kernels).
+template <int HD, int GQ, int NQ>
+static int tile_attn_t(ixt_ctx* c, int layer, int R, int lmax, size_t lds, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {   // up to 160 KiB of dynamic LDS: the attribute once per kernel
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_tile<HD, GQ, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    attr_done = true;
+  }
+  TileAttnArgs ta;
+  ta.row_slot = c->row_slot; ta.row_pos = c->row_pos; ta.row_active = c->row_active; ta.page_map = c->ps.page_map;
+  ta.qbuf = c->qbuf; ta.kpages = c->kpages_l[layer]; ta.vpages = c->vpages_l[layer]; ta.out = c->ao; ta.g = c->geom; ta.R = R; ta.lmax = lmax;
+  constexpr int TQ = NQ / GQ;
+  hipLaunchKernelGGL((k_attn_tile<HD, GQ, NQ>), dim3(c->geom.nkv, (R + TQ - 1) / TQ), dim3(256), lds, st, ta);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+static size_t tile_attn_lds(const ixt_ctx* c, int nq, int lmax) {
+  const int ppb = 4 * (64 / (c->D / 4));   // pages of a PV pass
+  return sizeof(float) * ((size_t)nq * lmax + (size_t)nq * ((c->geom.mpg + 3) & ~3) + (size_t)ppb * (nq / 2) * c->D);
+}
+static bool tile_attn_fits(const ixt_ctx* c, int R, int len_hint, bool decode) {
+  if (decode || !c->attn_tile || R < c->attn_tile_min_rows) return false;
+  const int lmax = (std::min(len_hint, c->Tmax) + 3) & ~3;
+  return tile_attn_lds(c, 8, lmax) <= 150 * 1024;
+}
+static int launch_attention_tile(ixt_ctx* c, int layer, int R, int len_hint, hipStream_t st) {
+  const int lmax = (std::min(len_hint, c->Tmax) + 3) & ~3;
+  const bool wide = tile_attn_lds(c, 16, lmax) <= 150 * 1024;
+  const size_t lds = tile_attn_lds(c, wide ? 16 : 8, lmax);
+#define ATT(HD_, GQ_)                                                                             \
+  if (c->D == HD_ && c->GQ == GQ_) return wide ? tile_attn_t<HD_, GQ_, 16>(c, layer, R, lmax, lds, st) : tile_attn_t<HD_, GQ_, 8>(c, layer, R, lmax, lds, st);
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "tiled attention: head_dim %d with %d query heads per kv head", c->D, c->GQ);
+}
+
 // decode rows, enough (row, kv head) pairs to fill the chip: the whole attention in one launch (writes c->ao)
 static int launch_attention_fused(ixt_ctx* c, int layer, int R, const DotResult& qkv, bool newtok, hipStream_t st) {
 #define ATT(HD_, GQ_)                                                                             \
@@ -912,6 +951,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
   const int fused_min = c->attn_fused_min_blocks;
   const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
   const bool attn_one_launch = R * c->KV >= fused_min && fused_lds <= 64 * 1024;
+  const bool attn_tiled = tile_attn_fits(c, R, len_hint, decode);   // prefill rows: consecutive rows share their page group's K and V loads
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
@@ -921,7 +961,9 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       e.row_slot = c->row_slot; e.row_pos = c->row_pos; e.row_active = c->row_active; e.page_map = c->ps.page_map;
       e.rope_sin = c->rope_sin; e.rope_cos = c->rope_cos; e.qbuf = c->qbuf; e.kpages = c->kpages_l[l]; e.vpages = c->vpages_l[l]; e.g = c->geom;
       TRY(launch_ring(c, GEPI_QKV, c->xn, w.wqkv, E, c->NQKV, R, e, false, st));
-      if (attn_one_launch) {
+      if (attn_tiled) {
+        TRY(launch_attention_tile(c, l, R, len_hint, st));
+      } else if (attn_one_launch) {
         const DotResult none{0, 0, 0};
         const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
         TRY(launch_attention_fused(c, l, R, none, false, st));   // q from qbuf, every key / value (the new ones too) from the pages
@@ -970,7 +1012,9 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       LAUNCHCHK();
     }
     // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
-    if (attn_one_launch) {   // decode rows, and prefill rows after k_qkv_finalize
+    if (attn_tiled) {
+      TRY(launch_attention_tile(c, l, R, len_hint, st));
+    } else if (attn_one_launch) {   // decode rows, and prefill rows after k_qkv_finalize
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;   // K/V bytes depend on the rows' lengths: the caller prices them
       TRY(launch_attention_fused(c, l, R, dr, decode, st));
       timing_end(c, st, ta);
@@ -1014,17 +1058,18 @@ extern "C" int ixt_prefill_chunk(ixt_ctx* c, int slot, const int32_t* tokens_dev
   return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, nullptr, first_token_dev, last_logits_dev, false, st);
 }
 
-extern "C" int ixt_prefill_rows(ixt_ctx* c, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev,
+extern "C" int ixt_prefill_rows(ixt_ctx* c, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev, int max_len,
                                 int n_logits, const int32_t* logits_rows_dev, int32_t* first_tokens_dev, float* logits_dev, void* stream) {
   if (!c || !tokens_dev || !row_group_dev || !row_pos_dev || !logits_rows_dev || !first_tokens_dev) return set_err(IXT_ERR_INVALID, "null argument");
   if (n_rows <= 0 || n_rows > c->Rmax) return set_err(IXT_ERR_RANGE, "packed prefill of %d rows (max %d: ixt_config.max_packed_rows)", n_rows, c->Rmax);
   if (n_logits <= 0 || n_logits > c->NLmax || n_logits > n_rows) return set_err(IXT_ERR_RANGE, "packed prefill with %d prompts (max %d)", n_logits, c->NLmax);
+  if (max_len <= 0 || max_len > c->Tmax) max_len = c->Tmax;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_rows_packed, dim3((n_rows + 255) / 256), dim3(256), 0, st, c->row_slot, c->row_pos, c->row_active, row_group_dev, row_pos_dev, n_rows,
-                     c->ps.num_pages_used, c->P, c->G, c->Tmax);
+                     c->ps.num_pages_used, c->P, c->G, c->Tmax, max_len, c->ps.status);
   LAUNCHCHK();
   HIPCHK(hipMemcpyAsync(c->lrows, logits_rows_dev, sizeof(int32_t) * n_logits, hipMemcpyDeviceToDevice, st));
-  return forward_rows(c, n_rows, tokens_dev, c->Tmax, 0, n_logits, c->lrows, first_tokens_dev, logits_dev, false, st);
+  return forward_rows(c, n_rows, tokens_dev, max_len, 0, n_logits, c->lrows, first_tokens_dev, logits_dev, false, st);
 }
 
 static int decode_rows(ixt_ctx* c, const int32_t* tokens_dev, const int32_t* pos_dev, int32_t* next_tokens_dev, float* logits_dev, int check_len,
@@ -1240,7 +1285,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
   const Opt opts[] = {
       {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
-      {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
+      {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0},
   };
   for (const Opt& o : opts) {

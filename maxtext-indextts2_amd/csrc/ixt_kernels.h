@@ -1566,6 +1566,314 @@ __global__ __launch_bounds__(256) void k_attn_decode_w(DecAttnArgs a, int npairs
 #undef IXT_VBATCH
 }
 
+// ---- prefill rows, tiled: block = (kv head, NQ / GQ consecutive rows).  Consecutive prefill rows belong to one page group, so their
+//      keys and values are the same pages: a tile loads every K row once (lane = key, the whole key unpacked to f32 registers) and runs
+//      the NQ query vectors over it, and every V batch once for NQ accumulator sets -- the per-row kernel above re-reads the group's
+//      pages for every row.  Same operation order per query vector as k_attn_decode: scores one fma chain over d, max, exp, page sums in
+//      key order, l in page order, P = bf16(e / l), PV page chains -> super-blocks of 4 pages in order -> super-blocks in order.
+//      Scores: the query operand of the chains is wave-uniform, so it comes by scalar loads (bf16 pairs expanded on the scalar unit, the
+//      next 32 d of both queries in flight while the current 32 are multiplied) -- no LDS traffic, no vector registers -- and two query
+//      vectors run as the two halves of packed f32 fmas.  Softmax: one wave per four query vectors, their phases interleaved.
+//      PV: lane = (page, 4 d), page chains for all NQ vectors in registers; the page sums meet in LDS, where the thread that owns
+//      (vector, d) adds them up four pages at a time and in order.  Rows of a tile that sit in different page groups (a tile across the
+//      border of two packed prompts) are worked off group by group.  grid = (nkv, ceil(R / TQ)), block 256;
+//      LDS = NQ x lmax scores + 4 x mpg page sums + (256 / (HD / 4)) x NQ / 2 x HD page chains.
+struct TileAttnArgs {
+  const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
+  const bf16_t* qbuf;                 // [R][nq][hd] finalised queries
+  const bf16_t* kpages; const bf16_t* vpages;
+  bf16_t* out;                        // [R][nq*hd] in xidx layout
+  AttnGeom g;
+  int R;
+  int lmax;                           // keys one score row holds (multiple of 4); a group reaching further is left to the caller's guard
+};
+typedef uint32_t ixt_u32x16 __attribute__((ext_vector_type(16)));
+typedef float ixt_f32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) ixt_u32x16* ixt_cq16p;   // constant address space: uniform reads become scalar loads
+
+template <int HD, int GQ, int NQ>
+__global__ __launch_bounds__(256, 2) void k_attn_tile(TileAttnArgs a) {
+  constexpr int TQ = NQ / GQ;             // rows of a tile
+  constexpr int LPG = HD / 4;             // PV: lanes per page (each 4 d)
+  constexpr int PPW = 64 / LPG;           // PV: pages a wave covers at once
+  constexpr int PPB = 4 * PPW;            // pages of a pass
+  constexpr int SBB = PPB / IXT_SB;       // super-blocks of a pass
+  constexpr int NQH = NQ / 2;             // the page chains go through LDS in two halves of the query vectors
+  constexpr int NT = NQH * HD / 256;      // (query vector, d) totals per thread and half
+  constexpr int NP = HD / 32;             // a query vector = NP scalar loads of 16 dwords
+  constexpr int QW = NQ / 4;              // query vectors per wave in the softmax phase
+  static_assert(NQ % GQ == 0 && NQ % 8 == 0 && TQ <= 32 && (NQH * HD) % 256 == 0 && PPB % IXT_SB == 0, "tile geometry");
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  __shared__ int s_pos[TQ], s_slot[TQ];
+  const AttnGeom& g = a.g;
+  const int kvh = blockIdx.x, r0 = blockIdx.y * TQ;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int n_out = g.nq * HD;
+  const int tp = a.lmax, mpgr = (g.mpg + 3) & ~3;
+  float* ebuf = sm;                                  // [NQ][tp] scores -> exps -> P
+  float* psum = ebuf + (size_t)NQ * tp;              // [NQ][mpgr]... one row per query vector of the wave in flight: [4 waves][QW][mpgr]
+  float* pgs = psum + (size_t)4 * QW * mpgr;         // [PPB][NQH][HD] page chains of one pass and half
+  if (tid < TQ) {
+    const int r = r0 + tid;
+    const bool ok = r < a.R && a.row_active[r] != 0;
+    s_pos[tid] = ok ? a.row_pos[r] : -1;
+    s_slot[tid] = ok ? a.row_slot[r] : -1;
+  }
+  __syncthreads();
+  unsigned pending = 0;
+#pragma unroll
+  for (int i = 0; i < TQ; ++i) {
+    const bool act = __builtin_amdgcn_readfirstlane(s_pos[i]) >= 0;
+    if (act) pending |= 1u << i;
+    else if (r0 + i < a.R) {                         // idle row: zeros, as the per-row kernel writes
+      for (int idx = tid; idx < GQ * HD; idx += 256) a.out[xidx(r0 + i, kvh * GQ * HD + idx, n_out)] = 0;
+    }
+  }
+  const int tq = lane / LPG, dq = lane % LPG;
+  while (pending != 0) {
+    // the rows of the leader's page group
+    const int lead = __builtin_ctz(pending);
+    const int slot = __builtin_amdgcn_readfirstlane(s_slot[lead]);
+    unsigned grp = 0;
+    int posmax = -1;
+#pragma unroll
+    for (int i = 0; i < TQ; ++i) {
+      const int ps_ = __builtin_amdgcn_readfirstlane(s_pos[i]), sl_ = __builtin_amdgcn_readfirstlane(s_slot[i]);
+      const bool in = ((pending >> i) & 1u) && sl_ == slot && ps_ < tp;
+      if (in) { grp |= 1u << i; posmax = max(posmax, ps_); }
+    }
+    if (((grp >> lead) & 1u) == 0) {                 // the leader reaches beyond the score rows (the caller's max_len guard prevents it): zeros
+      for (int idx = tid; idx < GQ * HD; idx += 256) a.out[xidx(r0 + lead, kvh * GQ * HD + idx, n_out)] = 0;
+      pending &= ~(1u << lead);
+      continue;
+    }
+    pending &= ~grp;
+    const int kv_all = posmax + 1, kv4 = min((kv_all + 3) & ~3, tp);
+    const int pages_all = (kv_all + g.P - 1) / g.P;
+    const int32_t* prow = a.page_map + (size_t)slot * g.mpg;
+
+    // ---- scores: lane = key, the key's HD values in registers; two query vectors per pass over them, one fma chain over d each
+    const int ntile = (kv_all + 63) >> 6;
+    for (int t = wave; t < ntile; t += 4) {
+      const int j = t * 64 + lane;
+      ixt_f32x2 kf[HD / 2];                              // (k[2c], k[2c+1]): one packed fma takes either half for both of its lanes (op_sel)
+      if (j < kv_all) {
+        const bf16_t* kp = a.kpages + kpage_off(g, prow[j / g.P], kvh, 0, j % g.P);
+#pragma unroll
+        for (int c = 0; c < HD / 8; ++c) {
+          const u32x4 kr = *reinterpret_cast<const u32x4*>(kp + (size_t)c * g.P * 8);
+          kf[c * 4 + 0] = (ixt_f32x2){bflo(kr.x), bfhi(kr.x)}; kf[c * 4 + 1] = (ixt_f32x2){bflo(kr.y), bfhi(kr.y)};
+          kf[c * 4 + 2] = (ixt_f32x2){bflo(kr.z), bfhi(kr.z)}; kf[c * 4 + 3] = (ixt_f32x2){bflo(kr.w), bfhi(kr.w)};
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < HD / 2; ++c) kf[c] = (ixt_f32x2){0.0f, 0.0f};
+      }
+      // query vectors (qv, qv + 1); rows past the end of the call read the last row (their scores are never stored)
+#define IXT_QPTR(QV_) ((ixt_cq16p)(a.qbuf + ((size_t)min(r0 + (QV_) / GQ, a.R - 1) * g.nq + kvh * GQ + (QV_) % GQ) * HD))
+      ixt_u32x16 ca = IXT_QPTR(0)[0], cb = IXT_QPTR(1)[0];
+      for (int qv = 0; qv < NQ; qv += 2) {
+        ixt_f32x2 acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int part = 0; part < NP; ++part) {
+          ixt_u32x16 na, nb;                                   // the next 32 d of both vectors (the next pair's first 32 after the last part)
+          if (part + 1 < NP) { na = IXT_QPTR(qv)[part + 1]; nb = IXT_QPTR(qv + 1)[part + 1]; }
+          else { const int nq_ = qv + 2 < NQ ? qv + 2 : 0; na = IXT_QPTR(nq_)[0]; nb = IXT_QPTR(nq_ + 1)[0]; }
+          __builtin_amdgcn_sched_barrier(0);                   // the loads are issued here, ahead of the 32 fmas that hide them
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            // acc.x += qa[d] k[d], acc.y += qb[d] k[d] for d = 2k (first) and 2k + 1 (second): the key operand is one half of the
+            // register pair for both lanes of the packed fma -- the compiler would copy it into a second register instead
+            const ixt_f32x2 qlo = {bflo(ca[k]), bflo(cb[k])}, qhi = {bfhi(ca[k]), bfhi(cb[k])};
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(qlo), "v"(kf[part * 16 + k]));
+            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(qhi), "v"(kf[part * 16 + k]));
+          }
+          ca = na; cb = nb;
+        }
+        const int i0 = qv / GQ, i1 = (qv + 1) / GQ;
+        const int p0 = ((grp >> i0) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i0]) : -1;
+        const int p1 = ((grp >> i1) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i1]) : -1;
+        if (j <= p0) ebuf[(size_t)qv * tp + j] = acc.x;
+        if (j <= p1) ebuf[(size_t)(qv + 1) * tp + j] = acc.y;
+      }
+#undef IXT_QPTR
+    }
+    __syncthreads();
+
+    // ---- softmax statistics: wave w owns query vectors w QW .. w QW + QW - 1 and walks them through the phases side by side
+    {
+      int kvl[QW];
+      float m[QW], l[QW];
+#pragma unroll
+      for (int u = 0; u < QW; ++u) {
+        const int i = (wave * QW + u) / GQ;
+        kvl[u] = ((grp >> i) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i]) + 1 : 0;
+        m[u] = -INFINITY;
+      }
+#pragma unroll
+      for (int u = 0; u < QW; ++u) {
+        const float* e = ebuf + (size_t)(wave * QW + u) * tp;
+        for (int j = lane; j < kvl[u]; j += 64) m[u] = fmaxf(m[u], e[j]);
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+#pragma unroll
+        for (int u = 0; u < QW; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], off, 64));
+      }
+#pragma unroll
+      for (int u = 0; u < QW; ++u) {
+        float* e = ebuf + (size_t)(wave * QW + u) * tp;
+        for (int j = lane; j < kvl[u]; j += 64) e[j] = ixt_exp(e[j] - m[u]);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // page sums in key order: one lane per (query vector, page), the wave's QW vectors side by side
+      {
+        int maxpages = 0;
+#pragma unroll
+        for (int u = 0; u < QW; ++u) maxpages = max(maxpages, (kvl[u] + g.P - 1) / g.P);
+        for (int it = lane; it < QW * maxpages; it += 64) {
+          const int u = it % QW, p = it / QW;
+          int kvl_u = kvl[0];
+#pragma unroll
+          for (int k = 1; k < QW; ++k) kvl_u = u == k ? kvl[k] : kvl_u;
+          const int n = min(g.P, kvl_u - p * g.P);
+          if (n > 0) {
+            const float* ep = ebuf + (size_t)(wave * QW + u) * tp + (size_t)p * g.P;
+            float sacc = 0.0f;
+            int t0 = 0;
+            for (; t0 + 8 <= n; t0 += 8) {
+              const float4 x0 = *reinterpret_cast<const float4*>(ep + t0), x1 = *reinterpret_cast<const float4*>(ep + t0 + 4);
+              sacc = sacc + x0.x; sacc = sacc + x0.y; sacc = sacc + x0.z; sacc = sacc + x0.w;
+              sacc = sacc + x1.x; sacc = sacc + x1.y; sacc = sacc + x1.z; sacc = sacc + x1.w;
+            }
+            for (; t0 < n; ++t0) sacc = sacc + ep[t0];
+            psum[(size_t)(wave * QW + u) * mpgr + p] = sacc;
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      // l in page order: lane u adds up vector u's page sums, every lane takes its copy
+      {
+        float lv = 0.0f;
+        if (lane < QW) {
+          int kvl_u = kvl[0];
+#pragma unroll
+          for (int k = 1; k < QW; ++k) kvl_u = lane == k ? kvl[k] : kvl_u;
+          const float* ps = psum + (size_t)(wave * QW + lane) * mpgr;
+          const int pages_q = (kvl_u + g.P - 1) / g.P;
+          int p = 0;
+          for (; p + 4 <= pages_q; p += 4) {
+            const float4 x0 = *reinterpret_cast<const float4*>(ps + p);
+            lv = lv + x0.x; lv = lv + x0.y; lv = lv + x0.z; lv = lv + x0.w;
+          }
+          for (; p < pages_q; ++p) lv = lv + ps[p];
+        }
+#pragma unroll
+        for (int u = 0; u < QW; ++u) l[u] = __shfl(lv, u, 64);
+      }
+#pragma unroll
+      for (int u = 0; u < QW; ++u) {
+        float* e = ebuf + (size_t)(wave * QW + u) * tp;
+        for (int j = lane; j < kvl[u]; j += 64) e[j] = rbf(e[j] / l[u]);
+        for (int j = kvl[u] + lane; j < kv4; j += 64) e[j] = 0.0f;   // the tile's keys this row does not see: weight 0 (see PV)
+      }
+    }
+    __syncthreads();
+
+    // ---- PV: lane = (page of the wave's group, 4 d); a V batch of 4 tokens feeds all NQ accumulator sets.  No masks: a key a row does not
+    //      see (a later row's key of the same tile) has P = +0, and fma(+0, v, acc) leaves acc as it is for every finite v -- a chain
+    //      that sees nothing stays +0, as the page the per-row kernel never enters.  (With an infinite or NaN V entry such a key would
+    //      turn up to 15 earlier rows into NaN; the model is lost at that point anyway.)
+    float tot[2 * NT];
+#pragma unroll
+    for (int k = 0; k < 2 * NT; ++k) tot[k] = 0.0f;
+    const int npass = (pages_all + PPB - 1) / PPB;
+    for (int pass = 0; pass < npass; ++pass) {
+      const int pl = wave * PPW + tq, p = pass * PPB + pl;
+      float acc[NQ][4];
+#pragma unroll
+      for (int qv = 0; qv < NQ; ++qv)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[qv][x] = 0.0f;
+      if (p < pages_all) {
+        const int nt = min(g.P, kv_all - p * g.P);
+        const bf16_t* vbase = a.vpages + vpage_off(g, prow[p], kvh, 0) + dq * 4;
+        uint2 raw[4], nxt[4];                          // the next batch's loads fly while this one is multiplied
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raw[u] = *reinterpret_cast<const uint2*>(vbase + (size_t)min(u, nt - 1) * HD);
+        for (int t0 = 0; t0 < nt; t0 += 4) {
+          // unconditional (a token past the page's end re-reads its last one and is never used): a fixed number of loads in flight lets the
+          // wait for the current batch leave the next one outstanding
+#pragma unroll
+          for (int u = 0; u < 4; ++u) nxt[u] = *reinterpret_cast<const uint2*>(vbase + (size_t)min(t0 + 4 + u, nt - 1) * HD);
+          float vf[4][4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            vf[u][0] = bflo(raw[u].x); vf[u][1] = bfhi(raw[u].x); vf[u][2] = bflo(raw[u].y); vf[u][3] = bfhi(raw[u].y);
+          }
+          const int j0 = p * g.P + t0;
+#pragma unroll
+          for (int q8 = 0; q8 < NQ; q8 += 8) {           // eight P reads in flight, then their 64 packed fmas
+            float4 p4[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) p4[k] = *reinterpret_cast<const float4*>(ebuf + (size_t)(q8 + k) * tp + j0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              const int qv = q8 + k;
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[qv][x] = __builtin_fmaf(p4[k].x, vf[0][x], acc[qv][x]);
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[qv][x] = __builtin_fmaf(p4[k].y, vf[1][x], acc[qv][x]);
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[qv][x] = __builtin_fmaf(p4[k].z, vf[2][x], acc[qv][x]);
+#pragma unroll
+              for (int x = 0; x < 4; ++x) acc[qv][x] = __builtin_fmaf(p4[k].w, vf[3][x], acc[qv][x]);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) raw[u] = nxt[u];   // only now: the copy waits for the loads
+        }
+      }
+      // the page chains meet in LDS, half of the query vectors at a time; the owner of (vector, d) adds four pages in order into the
+      // super-block sum and the super-block sums, in order, onto its total (a page past the row's range holds zeros, as in k_attn_decode)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int k = 0; k < NQH; ++k)
+          *reinterpret_cast<float4*>(pgs + ((size_t)pl * NQH + k) * HD + dq * 4) = make_float4(acc[h * NQH + k][0], acc[h * NQH + k][1], acc[h * NQH + k][2], acc[h * NQH + k][3]);
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < NT; ++k4) {
+          const int idx = tid + 256 * k4, k = idx / HD, d = idx % HD, qv = h * NQH + k;
+          const int pq = s_pos[qv / GQ];
+          const int nsb_q = ((grp >> (qv / GQ)) & 1u) ? ((pq + g.P) / g.P + IXT_SB - 1) / IXT_SB : 0;
+#pragma unroll
+          for (int s = 0; s < SBB; ++s) {
+            if (pass * SBB + s < nsb_q) {
+              float ss = 0.0f;
+#pragma unroll
+              for (int i = 0; i < IXT_SB; ++i) ss = ss + pgs[((size_t)(s * IXT_SB + i) * NQH + k) * HD + d];
+              tot[h * NT + k4] = tot[h * NT + k4] + ss;
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k4 = 0; k4 < NT; ++k4) {
+        const int idx = tid + 256 * k4, qv = h * NQH + idx / HD, d = idx % HD;
+        if ((grp >> (qv / GQ)) & 1u) a.out[xidx(r0 + qv / GQ, (kvh * GQ + qv % GQ) * HD + d, n_out)] = f2bf(tot[h * NT + k4]);
+      }
+    __syncthreads();                                 // ebuf / psum / pgs are reused by the next group
+  }
+}
+
 // ---- step 4: out = bf16(sum over super-blocks, in order).  grid = R, block 256.
 __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const int32_t* row_pos, const int32_t* row_active,
                                                       bf16_t* out, AttnGeom g, int kmajor) {
@@ -1606,12 +1914,15 @@ __global__ void k_rows_prefill(int32_t* row_slot, int32_t* row_pos, int32_t* row
   if (i < n) { row_slot[i] = slot; row_pos[i] = start + i; row_active[i] = (start + i) / P < num_pages_used[slot] ? 1 : 0; }
 }
 // caller-described rows (packed prefill): slot and position per row, same page guard; out-of-range descriptors make the row inactive
+// max_len: the caller's bound on position + 1 (it sizes the tiled attention's score rows); a row at or beyond it is idle and counted in
+// status[3] instead of being computed against a bound the caller did not mean.
 __global__ void k_rows_packed(int32_t* row_slot, int32_t* row_pos, int32_t* row_active, const int32_t* slot_in, const int32_t* pos_in, int n,
-                              const int32_t* num_pages_used, int P, int groups, int Tmax) {
+                              const int32_t* num_pages_used, int P, int groups, int Tmax, int max_len, int32_t* status) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     const int g = slot_in[i], pos = pos_in[i];
-    const bool ok = g >= 0 && g < groups && pos >= 0 && pos < Tmax;
+    const bool ok = g >= 0 && g < groups && pos >= 0 && pos < Tmax && pos < max_len;
+    if (g >= 0 && g < groups && pos >= max_len && pos < Tmax) atomicAdd(&status[3], 1);
     row_slot[i] = ok ? g : 0; row_pos[i] = ok ? pos : 0; row_active[i] = (ok && pos / P < num_pages_used[g]) ? 1 : 0;
   }
 }

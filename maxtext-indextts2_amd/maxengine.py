@@ -229,6 +229,7 @@ class MaxEngine(engine_api.Engine):
     toks = _as_device_i32(padded_tokens, self.device).reshape(-1)
     pos_all = _as_device_i32(decoder_positions, self.device).reshape(-1)
     total = sum(lens)
+    max_len = max(lens) if lens else 0     # positions of a prompt run 0 .. true_length - 1 (maxengine.py:746-760)
     if any(l <= 0 for l in lens) or any(st < 0 or st + l > toks.numel() for st, l in zip(starts, lens)):
       raise ValueError("prefill_concat: start_pos / true_lengths outside padded_tokens")
     if total > self._packed_rows:
@@ -246,7 +247,8 @@ class MaxEngine(engine_api.Engine):
     logits = torch.empty((n, 1, 1, V), dtype=torch.float32, device=self.device)
     first = torch.empty((n,), dtype=torch.int32, device=self.device)
     _lib.check(self.lib.ixt_prefill_rows(self._ctx, total, ctypes.c_void_p(row_tok.data_ptr()), ctypes.c_void_p(row_grp.data_ptr()),
-                                         ctypes.c_void_p(row_pos.data_ptr()), n, ctypes.c_void_p(ends.data_ptr()), ctypes.c_void_p(first.data_ptr()),
+                                         ctypes.c_void_p(row_pos.data_ptr()), max_len, n, ctypes.c_void_p(ends.data_ptr()),
+                                         ctypes.c_void_p(first.data_ptr()),
                                          ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
     next_pos = torch.tensor(lens, dtype=torch.int32, device=self.device).reshape(n, 1, 1)
     generated = torch.zeros((n, 1, 1), dtype=torch.int32, device=self.device)
