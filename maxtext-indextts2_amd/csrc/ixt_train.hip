@@ -188,7 +188,12 @@ static int gemm(hipStream_t st, const bf16_t* A, long sam, long sak, const bf16_
   g.C = C; g.scm = scm; g.scb1 = scb1; g.scb2 = scb2;
   g.M = M; g.N = N; g.K = K; g.nb2 = nb2; g.out_bf16 = out_bf16; g.accumulate = accumulate;
   if ((sam != 1 && sak != 1) || (sbk != 1 && sbn != 1)) return t_set_err(IXT_ERR_INVALID, "gemm: an operand has no unit stride");
-  hipLaunchKernelGGL(k_tgemm, dim3((N + 127) / 128, (M + 127) / 128, nb1 * nb2), dim3(256), 0, st, g);
+  const dim3 grid((N + 127) / 128, (M + 127) / 128, nb1 * nb2);
+  const bool ta = sak != 1, tb = sbk != 1;     // the operand's rows, not k, are contiguous: its tile is read transposed from LDS
+  if (ta && tb) hipLaunchKernelGGL((k_tgemm<true, true>), grid, dim3(256), 0, st, g);
+  else if (ta) hipLaunchKernelGGL((k_tgemm<true, false>), grid, dim3(256), 0, st, g);
+  else if (tb) hipLaunchKernelGGL((k_tgemm<false, true>), grid, dim3(256), 0, st, g);
+  else hipLaunchKernelGGL((k_tgemm<false, false>), grid, dim3(256), 0, st, g);
   TLAUNCH();
   return IXT_OK;
 }

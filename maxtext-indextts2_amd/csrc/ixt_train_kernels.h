@@ -13,8 +13,14 @@ typedef short tbf16x8 __attribute__((ext_vector_type(8)));
 // ---------------------------------------------------------------------------------------------------------------- general GEMM
 // C[m][n] (+)= sum_k A(m, k) B(k, n) for bf16 operands with arbitrary element strides (either index may be the contiguous one), f32
 // accumulation, two-level batch (z = z1 * nb2 + z2).  Block = 128 x 128 x 64, 4 waves as 2 x 2, wave = 64 x 64 = 4 x 4 MFMA tiles.
-// Both operand tiles go through LDS as [row][k] with k contiguous (rows padded to 72 elements: 16-byte aligned fragment reads,
-// conflict-light); a tile whose memory-contiguous index is not k is transposed on its way in (8 two-byte LDS stores per 16-byte load).
+// An operand tile lies in LDS the way it lies in memory, so every global 16-byte vector is one 16-byte LDS store:
+//   k contiguous  (TR = false): image [row][k], pitch 72 elements; a lane's fragment = two 8-byte reads
+//   row contiguous (TR = true):  image [k][row], pitch 144 elements; a lane's fragment = two ds_read_b64_tr_b16 (the LDS hands a 4 x 16 block
+//                                to 16 lanes column-wise: the transpose costs nothing; pitch 288 B puts the 8 k-rows a 32-lane half touches on
+//                                8 disjoint bank groups)
+// Both forms use ONE assignment of the 32 k of an MFMA to the lanes: lane group q (= lane / 16) holds k = 4q .. 4q+3 and 16+4q .. 16+4q+3
+// of the 32-block (the sum over k does not care which lane group carries which k, as long as both operands agree) -- with it the two
+// transposed reads of a half-wave cover 8 consecutive k-rows.
 // MFMA roles: A-operand = B tile rows (n), B-operand = A tile rows (m), so a lane ends with 4 consecutive n of one m.
 struct TGemm {
   const bf16_t* A; long sam, sak, sab1, sab2;
@@ -25,16 +31,19 @@ struct TGemm {
   int accumulate;                     // f32 output only: C += result
 };
 
-#define TG_LD 72     // LDS row pitch in elements: 64 k + 8 (16-byte aligned fragment reads, rows spread over the banks)
+#define TG_LD 72      // [row][k] image: 64 k + 8 elements of padding (144-byte rows)
+#define TG_LDT 144    // [k][row] image: 128 rows + 16 elements of padding (288-byte rows)
 #define TG_BK 64
+#define TG_TILE (64 * TG_LDT)   // elements of one operand image (the larger of 128 x 72 and 64 x 144: equal)
 // One operand tile = 128 rows x 64 k = 1024 vectors of 8 elements, 4 per thread: fetched into registers (tg_fetch) while the previous
 // tile is being multiplied, written to LDS afterwards (tg_store) -- the global latency runs under the MFMAs.
+template <bool TR>
 __device__ __forceinline__ void tg_fetch(u32x4 (&r)[4], const bf16_t* __restrict__ g, long s_row, long s_k, int row0, int k0, int nrows, int K, int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int v = tid + it * 256;
     r[it] = u32x4(0);
-    if (s_k == 1) {
+    if (!TR) {
       const int rr = v >> 3, kk = (v & 7) * 8;
       if (row0 + rr < nrows && k0 + kk < K) r[it] = *reinterpret_cast<const u32x4*>(g + (long)(row0 + rr) * s_row + (k0 + kk));
     } else {   // rows are the contiguous index (s_row == 1): 8 consecutive rows at one k per load
@@ -43,24 +52,40 @@ __device__ __forceinline__ void tg_fetch(u32x4 (&r)[4], const bf16_t* __restrict
     }
   }
 }
-__device__ __forceinline__ void tg_store(bf16_t* __restrict__ lds, const u32x4 (&r)[4], long s_k, int tid) {
+template <bool TR>
+__device__ __forceinline__ void tg_store(bf16_t* __restrict__ lds, const u32x4 (&r)[4], int tid) {
 #pragma unroll
   for (int it = 0; it < 4; ++it) {
     const int v = tid + it * 256;
-    if (s_k == 1) {
-      *reinterpret_cast<u32x4*>(lds + (v >> 3) * TG_LD + (v & 7) * 8) = r[it];
-    } else {
-      const int rr = (v & 15) * 8, kk = v >> 4;
-      const bf16_t* e = reinterpret_cast<const bf16_t*>(&r[it]);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) lds[(rr + j) * TG_LD + kk] = e[j];
-    }
+    if (!TR) *reinterpret_cast<u32x4*>(lds + (v >> 3) * TG_LD + (v & 7) * 8) = r[it];
+    else *reinterpret_cast<u32x4*>(lds + (v >> 4) * TG_LDT + (v & 15) * 8) = r[it];
   }
 }
+// the 8 k of lane group q for rows row0 .. row0 + 15 of a tile, k-block ks (see the k assignment above)
+template <bool TR>
+__device__ __forceinline__ void tg_frag_issue(uint2 (&f)[2], const bf16_t* lds, int row0, int ks, int lane) {
+  const int r_in = lane & 15, q = lane >> 4;
+  if constexpr (!TR) {
+    const bf16_t* p = lds + (row0 + r_in) * TG_LD + ks * 32 + 4 * q;
+    f[0] = *reinterpret_cast<const uint2*>(p);
+    f[1] = *reinterpret_cast<const uint2*>(p + 16);
+  } else {
+    // lane 4a + p of a 16-lane group: row (k) a of the block, columns (tile rows) 4p .. 4p+3
+    const bf16_t* p = lds + (ks * 32 + 4 * q + (r_in >> 2)) * TG_LDT + row0 + 4 * (r_in & 3);
+    const uint32_t addr = (uint32_t)(uintptr_t)((const __attribute__((address_space(3))) void*)(p));
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(f[0]) : "v"(addr) : "memory");
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(f[1]) : "v"(addr), "n"(16 * TG_LDT * 2) : "memory");
+  }
+}
+__device__ __forceinline__ tbf16x8 tg_frag(const uint2 (&f)[2]) {
+  u32x4 v; v.x = f[0].x; v.y = f[0].y; v.z = f[1].x; v.w = f[1].y;
+  return __builtin_bit_cast(tbf16x8, v);
+}
 
+template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void k_tgemm(TGemm g) {
-  __shared__ __attribute__((aligned(16))) bf16_t As[128 * TG_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t Bs[128 * TG_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t As[TG_TILE];
+  __shared__ __attribute__((aligned(16))) bf16_t Bs[TG_TILE];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int z1 = blockIdx.z / g.nb2, z2 = blockIdx.z % g.nb2;
   const bf16_t* A = g.A + z1 * g.sab1 + z2 * g.sab2;
@@ -74,23 +99,32 @@ __global__ __launch_bounds__(256) void k_tgemm(TGemm g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = tf32x4(0.0f);
   u32x4 ra[4], rbv[4];
-  tg_fetch(ra, A, g.sam, g.sak, m0, 0, g.M, g.K, tid);
-  tg_fetch(rbv, B, g.sbn, g.sbk, n0, 0, g.N, g.K, tid);
+  tg_fetch<TA>(ra, A, g.sam, g.sak, m0, 0, g.M, g.K, tid);
+  tg_fetch<TB>(rbv, B, g.sbn, g.sbk, n0, 0, g.N, g.K, tid);
   for (int k0 = 0; k0 < g.K; k0 += TG_BK) {
-    tg_store(As, ra, g.sak, tid);
-    tg_store(Bs, rbv, g.sbk, tid);
+    tg_store<TA>(As, ra, tid);
+    tg_store<TB>(Bs, rbv, tid);
     __syncthreads();
     if (k0 + TG_BK < g.K) {                       // the next tile's loads fly while this one is multiplied
-      tg_fetch(ra, A, g.sam, g.sak, m0, k0 + TG_BK, g.M, g.K, tid);
-      tg_fetch(rbv, B, g.sbn, g.sbk, n0, k0 + TG_BK, g.N, g.K, tid);
+      tg_fetch<TA>(ra, A, g.sam, g.sak, m0, k0 + TG_BK, g.M, g.K, tid);
+      tg_fetch<TB>(rbv, B, g.sbn, g.sbk, n0, k0 + TG_BK, g.N, g.K, tid);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
+      uint2 fa[4][2], fb[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tg_frag_issue<TA>(fa[i], As, wr * 64 + i * 16, ks, lane);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tg_frag_issue<TB>(fb[j], Bs, wc * 64 + j * 16, ks, lane);
+      // the transposed reads are issued by hand: the compiler neither counts them nor knows that their registers fill late -- the wait
+      // takes the fragment registers as operands, so nothing that uses them can be scheduled ahead of it
+      if constexpr (TA) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0][0]), "+v"(fa[0][1]), "+v"(fa[1][0]), "+v"(fa[1][1]), "+v"(fa[2][0]), "+v"(fa[2][1]), "+v"(fa[3][0]), "+v"(fa[3][1]) :: "memory");
+      if constexpr (TB) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[0][0]), "+v"(fb[0][1]), "+v"(fb[1][0]), "+v"(fb[1][1]), "+v"(fb[2][0]), "+v"(fb[2][1]), "+v"(fb[3][0]), "+v"(fb[3][1]) :: "memory");
       tbf16x8 af[4], bf[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const tbf16x8*>(As + (wr * 64 + i * 16 + r_in) * TG_LD + ks * 32 + q * 8);
+      for (int i = 0; i < 4; ++i) af[i] = tg_frag(fa[i]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const tbf16x8*>(Bs + (wc * 64 + j * 16 + r_in) * TG_LD + ks * 32 + q * 8);
+      for (int j = 0; j < 4; ++j) bf[j] = tg_frag(fb[j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
