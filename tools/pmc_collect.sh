@@ -10,7 +10,7 @@ OUT=$REPO/gpurun_out/pmc
 mkdir -p $OUT
 export TMPDIR=/tmp
 ARGS="--steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-batch-rows --no-detail --no-graph --sync-every 1 --prefill-len 768 --decode-steps ${PMC_STEPS:-6} --prefill-pack 8"
-REGEX='k_attn_decode|k_gemm_ring|k_gemm<'
+REGEX='k_attn_decode|k_attn_tile|k_gemm_ring|k_gemm<'
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"; do
   tag=$(echo $grp | cut -d' ' -f1)
   rm -rf $OUT/$tag
