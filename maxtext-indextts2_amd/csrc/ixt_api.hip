@@ -88,8 +88,7 @@ struct ixt_ctx {
   // MLP down-projection on the ring path: 1 = ring GEMM with the residual epilogue; 0 = split-K tiles (one f32 slice per 512-k chain, two blocks
   // per CU) + slice-sum / residual / norm kernel; -1 (default) = by shape: the ring form needs at least 192 whole-K blocks of 128 x 128 or 128 x 64
   int ring_down = -1;
-  int unembed_tall = 1;
-  int ring_ws = 0;   // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
+  int unembed_tall = 1;   // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
   int attn_tile = 1;         // prefill rows: tiled attention (k_attn_tile) from attn_tile_min_rows rows on
   int attn_tile_min_rows = 64;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
@@ -508,18 +507,18 @@ static int ring_pick(const ixt_ctx* c, int epi, int R, int N) {
   return 3;
 }
 
-template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT, int NL = 0>
+template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT>
 static int ring_launch_t(const bf16_t* x, const bf16_t* w, int K, int N, int R, int chains, int wring, const GemmEpi& e, hipStream_t st, int* wave_cols) {
   constexpr int TC = WC * CT, TR = WR * RB;
   const int ncolg = (N / 16 + TC - 1) / TC, zb = (R + 16 * TR - 1) / (16 * TR);
-  constexpr size_t lds = (size_t)NS * (TC + TR) * KS * 1024 + (NL ? 64 : 0);   // NL: the slots' full / done counters behind the ring
+  constexpr size_t lds = (size_t)NS * (TC + TR) * KS * 1024;
   static bool attr_done = false;
   if (!attr_done) {   // more than 64 KiB of dynamic LDS needs the attribute once per kernel
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT, NL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_done = true;
   }
   dim3 grid(((ncolg + 7) / 8) * 8 * zb, SPLIT ? chains : 1, 1);
-  hipLaunchKernelGGL((k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT, NL>), grid, dim3((WR * WC + NL) * 64), lds, st, reinterpret_cast<const u32x4*>(x),
+  hipLaunchKernelGGL((k_gemm_ring<WR, WC, RB, CT, KS, NS, EPI, SPLIT>), grid, dim3(WR * WC * 64), lds, st, reinterpret_cast<const u32x4*>(x),
                      reinterpret_cast<const u32x4*>(w), K, N, R, ncolg, zb, wring, e);
   LAUNCHCHK();
   if (wave_cols) *wave_cols = WC * ncolg;
@@ -543,11 +542,9 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   }
   const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0 + ebytes);
   int rc = IXT_ERR_UNSUPPORTED;
-#define RING_ARGS x, w, K, N, R, chains, wring, e, st, wave_cols
-  const bool ws = c->ring_ws != 0;   // wave-specialised: 4 loader waves beside the compute waves, no block barrier in the loop
-#define RING_A(EPI_, SPLIT_) (ws ? ring_launch_t<2, 4, 4, 2, 2, 4, EPI_, SPLIT_, 4>(RING_ARGS) : ring_launch_t<2, 4, 4, 2, 2, 4, EPI_, SPLIT_>(RING_ARGS))
-#define RING_B(EPI_) (ws ? ring_launch_t<2, 4, 4, 1, 2, 5, EPI_, 0, 4>(RING_ARGS) : ring_launch_t<2, 4, 4, 1, 2, 5, EPI_, 0>(RING_ARGS))
-#define RING_C(EPI_) (ws ? ring_launch_t<2, 2, 2, 1, 4, 6, EPI_, 0, 4>(RING_ARGS) : ring_launch_t<2, 2, 2, 1, 4, 6, EPI_, 0>(RING_ARGS))
+#define RING_A(EPI_, SPLIT_) ring_launch_t<2, 4, 4, 2, 2, 4, EPI_, SPLIT_>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+#define RING_B(EPI_) ring_launch_t<2, 4, 4, 1, 2, 5, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+#define RING_C(EPI_) ring_launch_t<2, 2, 2, 1, 4, 6, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
 #define RING(EPI_) do { if (cfg == 1) rc = RING_A(EPI_, 0); else if (cfg == 2) rc = RING_B(EPI_); else rc = RING_C(EPI_); } while (0)
   if (epi == GEPI_F32 && split) rc = RING_A(GEPI_F32, 1);
   else if (epi == GEPI_F32) RING(GEPI_F32);
@@ -556,18 +553,17 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   else if (epi == GEPI_UNEMBED) {
     // the unembedding at 129..256 rows: ONE block owns all rows of its 128 columns (8 waves of 64 x 64: 256 x 128 tile, 3 slots of 48 KiB), so the
     // 1 GB kernel enters the chip once instead of once per 128-row group
-    if (c->unembed_tall && R > 128 && R <= 256) rc = ws ? ring_launch_t<4, 2, 4, 4, 2, 3, GEPI_UNEMBED, 0, 4>(RING_ARGS) : ring_launch_t<4, 2, 4, 4, 2, 3, GEPI_UNEMBED, 0>(RING_ARGS);
+    if (c->unembed_tall && R > 128 && R <= 256) rc = ring_launch_t<4, 2, 4, 4, 2, 3, GEPI_UNEMBED, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);
     else rc = RING_A(GEPI_UNEMBED, 0);
   }
   else if (epi == GEPI_SWIGLU) {
     if (cfg == 1) rc = RING_A(GEPI_SWIGLU, 0);
-    else rc = ws ? ring_launch_t<2, 2, 4, 2, 2, 5, GEPI_SWIGLU, 0, 4>(RING_ARGS) : ring_launch_t<2, 2, 4, 2, 2, 5, GEPI_SWIGLU, 0>(RING_ARGS);   // gate pairs need two tiles per wave: 4 waves
+    else rc = ring_launch_t<2, 2, 4, 2, 2, 5, GEPI_SWIGLU, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);   // gate pairs need two tiles per wave: 4 waves
   }
 #undef RING
 #undef RING_A
 #undef RING_B
 #undef RING_C
-#undef RING_ARGS
   timing_end(c, st, ti);
   if (rc == IXT_ERR_UNSUPPORTED) return set_err(rc, "ring gemm: epilogue %d", epi);
   return rc;
@@ -1290,7 +1286,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
-      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_ws", &c->ring_ws, 0},
+      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

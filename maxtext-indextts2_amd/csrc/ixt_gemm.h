@@ -47,28 +47,10 @@ __device__ __forceinline__ void ring_wait() {
 
 //   grid = (8 ceil(ncolg / 8) zb, SPLIT ? chains : 1), block 64 WR WC, dynamic LDS = NS (WC CT + WR RB) KS KiB.
 //   Row groups of one column group are block ids b, b + 8, ..: same XCD, the weights meet in its L2.
-// NL > 0: wave-specialised form.  NL extra LOADER waves do nothing but issue the LDS-DMA loads; the WR x WC COMPUTE waves never issue one.
-// A wave issues in order, and an LDS-DMA load holds its wave for ~75 cycles in the memory pipe's queue (tools/ring_probe.hip) -- issued by a
-// compute wave that is ~300 of a chunk's ~600 cycles in which it starts no MFMA.  There is no block barrier in the loop either: a slot
-// carries two counters in LDS, `full` (loaders: "my share of the chunk has landed", after the counted vmcnt wait) and `done` (compute waves:
-// "I have read it"), so waves drift up to the ring depth apart instead of meeting once per chunk.
-template <int N_>
-__device__ __forceinline__ void ring_wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
-}
-// wait until *flag >= target; bounded (a logic error ends as a wrong result that the parity tests see, never as a hung GPU)
-__device__ __forceinline__ void ring_spin(const uint32_t* flag, uint32_t target, uint32_t* abort_flag) {
-  int guard = 0;
-  while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < target) {
-    __builtin_amdgcn_s_sleep(1);
-    if (++guard > (1 << 18)) { if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) || guard > (1 << 21)) { __hip_atomic_store(abort_flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); break; } }
-  }
-}
-
-template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT, int NL = 0>
-__global__ __launch_bounds__((WR * WC + NL) * 64, NL ? 1 : 2) void k_gemm_ring(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
+template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT>
+__global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                                int ncolg, int zb, int wring, GemmEpi e) {
-  constexpr int NW = WR * WC;          // (compute) waves
+  constexpr int NW = WR * WC;          // waves
   constexpr int TC = WC * CT;          // column tiles of a block
   constexpr int TR = WR * RB;          // row blocks of a block
   constexpr int NWF = TC * KS;         // weight fragments of a chunk
@@ -104,101 +86,6 @@ __global__ __launch_bounds__((WR * WC + NL) * 64, NL ? 1 : 2) void k_gemm_ring(c
   constexpr int CPC = 16 / KS;                                  // chunks per 512-k chain
   const int chb = SPLIT ? (int)blockIdx.y * CPC : 0;
   const int che = SPLIT ? min(nchunks, chb + CPC) : nchunks;
-  f32x4 acc[CT][RB], tot[CT][RB];
-#pragma unroll
-  for (int i = 0; i < CT; ++i)
-#pragma unroll
-    for (int b = 0; b < RB; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
-  if constexpr (NL > 0) {
-    constexpr int NJL = NF / NL;       // fragments a loader fetches per chunk
-    constexpr int LAG = NS - 1;        // chunks a loader keeps in flight
-    static_assert(NF % NL == 0 && LAG * NJL < 64, "loader geometry");
-    // 16 words behind the ring (in the dynamic region: a static array in front of it would move the ring off its 16-byte alignment)
-    uint32_t* s_full = reinterpret_cast<uint32_t*>(st + (size_t)NS * NF * 64);
-    uint32_t* s_done = s_full + 8;
-    uint32_t* s_abort_p = s_full + 15;
-    static_assert(NS <= 7, "flag block");
-    if (tid < 16) s_full[tid] = 0;
-    __syncthreads();
-    const int nch = che - chb;
-    if (wave >= NW) {
-      // ---------------------------------------------------------------- loader wave l: fragments l, l + NL, ..
-      const int l = wave - NW;
-      const u32x4* ls[NJL];
-#pragma unroll
-      for (int j = 0; j < NJL; ++j) {
-        const int f = l + NL * j;
-        if (f < NWF) {
-          const int tile = wring ? colg * TC + f / KS : min(colg * TC + f / KS, ntile - 1);
-          ls[j] = wt + (wring ? r8frag(tile, f % KS, nsteps) : (size_t)tile * nsteps + (f % KS)) * 64 + lane + (size_t)chb * wadv;
-        } else {
-          const int rb = min(rowg * TR + (f - NWF) / KS, nrbk - 1);
-          ls[j] = xt + ((size_t)rb * nsteps + ((f - NWF) % KS)) * 64 + lane + (size_t)chb * KS * 64;
-        }
-      }
-      int slot_i = 0, gen = 0;                                  // slot and generation of the chunk being issued
-      int slot_p = 0;                                           // slot of the next chunk to publish
-      for (int c = 0; c < nch; ++c) {
-        if (gen > 0) ring_spin(&s_done[slot_i], (uint32_t)(NW * gen), s_abort_p);   // every compute wave has read the slot's previous chunk
-#pragma unroll
-        for (int j = 0; j < NJL; ++j) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ls[j],
-                                           (__attribute__((address_space(3))) void*)(st + (slot_i * NF + l + NL * j) * 64), 16, 0, 0);
-          ls[j] += (l + NL * j < NWF) ? wadv : (size_t)KS * 64;
-        }
-        if (c >= LAG) {                                         // chunk c - LAG has landed once at most LAG chunks' loads are outstanding
-          ring_wait_vm<LAG * NJL>();
-          __hip_atomic_fetch_add(&s_full[slot_p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          slot_p = slot_p + 1 == NS ? 0 : slot_p + 1;
-        }
-        if (++slot_i == NS) { slot_i = 0; ++gen; }
-      }
-#pragma unroll
-      for (int k = LAG - 1; k >= 0; --k) {                      // the last min(LAG, nch) chunks
-        if (k < nch) {
-          if (k == LAG - 1) ring_wait_vm<(LAG - 1) * NJL>();
-          else if (k == 0) ring_wait_vm<0>();
-          else if (k == 1) ring_wait_vm<1 * NJL>();
-          else if (k == 2) ring_wait_vm<(LAG > 2 ? 2 : 0) * NJL>();
-          else ring_wait_vm<0>();
-          __hip_atomic_fetch_add(&s_full[slot_p], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          slot_p = slot_p + 1 == NS ? 0 : slot_p + 1;
-        }
-      }
-      return;
-    }
-    // ------------------------------------------------------------------ compute wave
-    int slot_c = 0, gen_c = 0;
-    for (int c = 0; c < nch; ++c) {
-      const int ch = chb + c;
-      ring_spin(&s_full[slot_c], (uint32_t)(NL * (gen_c + 1)), s_abort_p);
-      const u32x4* sb = st + (size_t)slot_c * NF * 64;
-      bf16x8 wf[KS][CT], xf[KS][RB];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int i = 0; i < CT; ++i) wf[ks][i] = __builtin_bit_cast(bf16x8, sb[((wc * CT + i) * KS + ks) * 64 + lane]);
-#pragma unroll
-        for (int b = 0; b < RB; ++b) xf[ks][b] = __builtin_bit_cast(bf16x8, sb[(NWF + (wr * RB + b) * KS + ks) * 64 + lane]);
-      }
-      // the LDS serves a wave's operations in order: when this add is performed the reads above have left the slot
-      asm volatile("" ::: "memory");
-      __hip_atomic_fetch_add(&s_done[slot_c], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-        for (int i = 0; i < CT; ++i)
-#pragma unroll
-          for (int b = 0; b < RB; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][b], acc[i][b], 0, 0, 0);
-      if (((ch + 1) % CPC) == 0 || ch + 1 == che) {             // a 512-k chain is complete
-#pragma unroll
-        for (int i = 0; i < CT; ++i)
-#pragma unroll
-          for (int b = 0; b < RB; ++b) { tot[i][b] = tot[i][b] + acc[i][b]; acc[i][b] = f32x4(0.0f); }
-      }
-      if (++slot_c == NS) { slot_c = 0; ++gen_c; }
-    }
-  } else {
 #define IXT_RISSUE(CH_, SLOT_)                                                                                         \
   do {                                                                                                                 \
     _Pragma("unroll") for (int j = 0; j < NJ; ++j)                                                                     \
@@ -208,6 +95,11 @@ __global__ __launch_bounds__((WR * WC + NL) * 64, NL ? 1 : 2) void k_gemm_ring(c
 #pragma unroll
   for (int c = 0; c < D; ++c)
     if (chb + c < che) IXT_RISSUE(chb + c, c);
+  f32x4 acc[CT][RB], tot[CT][RB];
+#pragma unroll
+  for (int i = 0; i < CT; ++i)
+#pragma unroll
+    for (int b = 0; b < RB; ++b) { acc[i][b] = f32x4(0.0f); tot[i][b] = f32x4(0.0f); }
   int slot = 0;                                                 // ring slot of chunk ch
 #ifdef IXT_RING_STAMPS   // diagnostic build (tools/ring_probe.hip): where an iteration spends its cycles; never defined in the product
   unsigned long long st0 = 0, st1 = 0, st2 = 0, st3 = 0, st4 = 0, sum_wait = 0, sum_bar = 0, sum_issue = 0, sum_comp = 0;
@@ -281,7 +173,6 @@ __global__ __launch_bounds__((WR * WC + NL) * 64, NL ? 1 : 2) void k_gemm_ring(c
 #endif
 #undef IXT_STAMP
 #undef IXT_RISSUE
-  }
 
   // ---------------------------------------------------------------- epilogues
   if constexpr (EPI == GEPI_F32) {
