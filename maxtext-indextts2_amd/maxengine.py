@@ -125,12 +125,15 @@ class MaxEngine(engine_api.Engine):
     """maxengine.py:218-271.  `params`: {MaxText tree path: array}; arrays may be torch (bf16/f32), numpy float32 or
     numpy uint16 (bf16 bit patterns).  With params=None and load_parameters_path == "" the weights are random-init
     (seed `ixt_synthetic_seed`), as the reference's setup_decode_state does (maxtext_utils.py:917-922)."""
+    self._param_source = ("tree", params)       # what set_engine_vars_from_base_engine replays into a second engine
     if params is None:
       path = self.config.load_parameters_path
       if path:
         params = _load_checkpoint(path)
+        self._param_source = ("path", path)
       else:
         params = _synth.synth_weights(self.config, int(self.config.ixt_synthetic_seed))
+        self._param_source = ("synthetic", int(self.config.ixt_synthetic_seed))
     st = _stream_ptr()
     for name, arr in params.items():
       t, dtype = _to_device_tensor(arr, self.device)
@@ -205,8 +208,21 @@ class MaxEngine(engine_api.Engine):
     }
     return prefix, result
 
-  def prefill_multisampling(self, *args, **kwargs):
-    raise NotImplementedError("prefill_multisampling (maxengine.py:595) is outside the built path (greedy only)")
+  def prefill_multisampling(self, *, params: Params, padded_tokens: Any, true_length: int, sampler: Any = None, rng: Any = None,
+                            num_samples: int = 1, slot: Optional[int] = None) -> Tuple[Prefix, engine_api.ResultTokens]:
+    """maxengine.py:595-717: one prefill, `num_samples` first tokens drawn from the same last-row logits.  Under the built sampling
+    strategy (greedy, inference_utils.py:74-75) every draw is the argmax, so the samples are equal; the shapes are the reference's:
+    tokens / generated_tokens [num_samples, 1], ResultTokens.data [num_samples, 3] with samples_per_slot = num_samples, one cache."""
+    num_samples = int(num_samples)
+    if num_samples < 1:
+      raise ValueError(f"num_samples ({num_samples}) must be at least 1")
+    prefix, _ = self.prefill(params=params, padded_tokens=padded_tokens, true_length=true_length, sampler=sampler, rng=rng, slot=slot)
+    first = prefix["tokens"].expand(num_samples, 1).contiguous()
+    generated = torch.zeros((num_samples, 1), dtype=torch.int32, device=self.device)
+    data = torch.cat([first, torch.ones_like(first), generated], dim=1)
+    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=num_samples)
+    prefix = dict(prefix, tokens=first, generated_tokens=generated)
+    return prefix, result
 
   def prefill_concat(self, *, params: Params, existing_prefix: Optional[ExistingPrefix] = None, padded_tokens: Any, decoder_positions: Any,
                      decoder_segment_ids: Any, start_pos: Any, true_lengths: Any, num_prompts: int, sampler: Any = None, rng: Any = None,
@@ -435,7 +451,42 @@ def _load_checkpoint(path: str) -> Dict[str, Any]:
   raise ValueError(f"load_parameters_path {path}: expected .safetensors or .npz")
 
 
-def create_engine_from_config_flags(config, **kwargs) -> MaxEngine:
-  """maxengine.py:1509."""
-  del kwargs
-  return MaxEngine(config)
+def set_engine_vars_from_base_engine(engine: MaxEngine, base_engine: MaxEngine, rng: Any = None) -> None:
+  """maxengine.py:1490-1506: a second engine takes over what the base engine has already set up after loading the checkpoint.  There it
+  is sharding / cache annotations; here the one thing an engine holds besides its own pages is the loaded weights, which each ixt context
+  keeps in its own layout -- so the base engine's parameters are loaded into `engine` (a device-to-device copy)."""
+  del rng
+  source = getattr(base_engine, "_param_source", None)
+  if source is None or not getattr(base_engine, "_params_loaded", False):
+    raise ValueError("set_engine_vars_from_base_engine: the base engine has no parameters loaded")
+  kind, what = source
+  if kind == "tree":
+    engine.load_params(params=what)
+  elif kind == "path":
+    engine.load_params(params=_load_checkpoint(what))
+  else:
+    engine.load_params(params=_synth.synth_weights(engine.config, what))
+
+
+def create_engine_from_config_flags(maxengine_config_filepath, batch_size, max_prefill_predict_length, max_target_length, args_str) -> MaxEngine:
+  """maxengine.py:1509-1545: a new engine with the given batch size and lengths plus the `k=v` pairs of args_str (load_parameters_path
+  among them, as the reference asserts).  The reference's defaults that select parallelism or the dense dot-product cache have no
+  counterpart here: this engine is one GPU and attention="paged"."""
+  from . import pyconfig  # pylint: disable=import-outside-toplevel
+  args = {
+      "scan_layers": "false",
+      "attention": "paged",
+      "max_prefill_predict_length": f"{max_prefill_predict_length}",
+      "max_target_length": f"{max_target_length}",
+      "per_device_batch_size": f"{batch_size}",
+  }
+  for item in (args_str or "").split(" "):
+    if item:
+      k, v = item.split("=")
+      args[k.strip()] = v.strip()
+  if "load_parameters_path" not in args:
+    raise AssertionError("load_parameters_path must be defined")
+  if maxengine_config_filepath is None:
+    maxengine_config_filepath = os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")
+  argv = ["maxengine_server.py", maxengine_config_filepath] + [f"{k}={v}" for k, v in args.items()]
+  return MaxEngine(pyconfig.initialize(argv))

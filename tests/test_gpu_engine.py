@@ -420,3 +420,57 @@ def test_page_pool_exhaustion_is_reported_and_harmless():
   k0, _ = eng.gather_kv(0, 0, 40)
   ko, _ = orc.model.gather_kv(0, orc.page_state.page_map[0], 40)
   assert np.array_equal(H.bits(k0), ko)
+
+
+def test_prefill_multisampling_greedy():
+  """maxengine.py:595-717 under greedy sampling: num_samples equal first tokens, the reference's result shapes, one cache."""
+  import torch
+  cfg = H.make_config(per_device_batch_size=2.0)
+  w = H.synth.synth_weights(cfg, 5)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  toks, tl = H.synth.synth_prompt(cfg.vocab_size, 32, 41)
+  pre, res = eng.prefill_multisampling(params=params, padded_tokens=toks, true_length=tl, num_samples=3, slot=1)
+  opre, ores = orc.prefill(toks, tl, slot=1, want_logits=True)
+  data = res.data.cpu().numpy()
+  assert data.shape == (3, 3) and res.samples_per_slot == 3
+  assert np.array_equal(data, np.repeat(ores, 3, axis=0))
+  assert pre["tokens"].shape == (3, 1) and pre["generated_tokens"].shape == (3, 1) and int(pre["next_pos"][0, 0]) == tl
+  assert np.array_equal(pre["logits"].cpu().numpy().reshape(-1).view(np.uint32), opre["logits"].reshape(-1).view(np.uint32))
+  with pytest.raises(ValueError):
+    eng.prefill_multisampling(params=params, padded_tokens=toks, true_length=tl, num_samples=0)
+  del eng
+  torch.cuda.synchronize()
+
+
+def test_engine_factory_helpers(tmp_path):
+  """create_engine_from_config_flags (maxengine.py:1509-1545: positional batch / lengths + "k=v" string, load_parameters_path required) and
+  set_engine_vars_from_base_engine (:1490-1506): the second engine decodes exactly like the first."""
+  import torch
+  maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
+  cfg = H.make_config(per_device_batch_size=2.0)
+  w = H.synth.synth_weights(cfg, 5)
+  path = str(tmp_path / "w.npz")
+  np.savez(path, **w)
+  with pytest.raises(AssertionError):
+    maxengine.create_engine_from_config_flags(None, 2, 32, 96, "model_name=ixt-tiny")
+  a = maxengine.create_engine_from_config_flags(None, 2, 32, 96, f"model_name=ixt-tiny load_parameters_path={path} pagedattn_num_pages=16")
+  assert a.max_concurrent_decodes == 2 and a.max_prefill_length == 32
+  pa = a.load_params()
+  b = maxengine.MaxEngine(a.config)
+  with pytest.raises(ValueError):
+    maxengine.set_engine_vars_from_base_engine(b, maxengine.MaxEngine(a.config))
+  maxengine.set_engine_vars_from_base_engine(b, a)
+  toks, tl = H.synth.synth_prompt(a.config.vocab_size, 32, 7)
+  outs = []
+  for eng in (a, b):
+    pre, res = eng.prefill(params=pa, padded_tokens=toks, true_length=tl, slot=0)
+    ds = eng.insert(pre, eng.init_decode_state(), 0)
+    seq = [int(res.data[0, 0])]
+    for _ in range(8):
+      ds, r = eng.generate(pa, ds)
+      seq.append(int(r.data[0, 0]))
+    outs.append(seq)
+  assert outs[0] == outs[1]
+  del a, b
+  torch.cuda.synchronize()
