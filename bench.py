@@ -272,6 +272,8 @@ def run_rank(args):
     out["roofline"] = None if args.no_roofline else roofline(args, wl, eng, cfg, nums, prompts, B)
     _log("live roofline done")
     if not args.no_batch_rows:
+      _log("long-prompt chunked prefill row")
+      out["detail"]["long_prefill"] = long_prefill_row(args, weights, nums)
       out["detail"]["batch_rows"] = []
       for b in (1, 8):
         out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
@@ -395,6 +397,42 @@ def batch_row(args, b, weights, prompts_dev, nums):
   return {"utterances": b, "tokens_per_s": b * (args.decode_steps + 1) / (t2 - t0), "decode_ms_per_step": ms_step, "decode_tokens_per_s": b / (ms_step * 1e-3),
           "prefill_ms_per_utterance": (t1 - t0) / b * 1e3, "decode_hbm_frac": step_bytes / (ms_step * 1e-3) / HBM_PEAK,
           "hbm_bound_tokens_per_s": bound}
+
+
+def long_prefill_row(args, weights, nums, total=4096):
+  """BASELINE.json configs[3]'s prefill shape on the C2 model: ONE prompt of `total` tokens through the engine's chunked prefill (chunks of
+  --prefill-len rows; each chunk attends to everything before it through the pages: k_attn_tile with a growing key range)."""
+  import numpy as np
+  import torch
+  pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
+  maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
+  synth = importlib.import_module("maxtext-indextts2_amd.synth")
+  P = args.prefill_len
+  cfg = pyconfig.initialize(["bench", os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")], model_name=args.model, attention="paged", scan_layers=False,
+                            per_device_batch_size=1.0, max_prefill_predict_length=P, max_target_length=total + 32, pagedattn_tokens_per_page=32,
+                            pagedattn_num_pages=(total + 32) // 32 + 2, ixt_use_hip_graph=False, run_name="bench", use_chunked_prefill=True,
+                            prefill_chunk_size=P)
+  eng = maxengine.MaxEngine(cfg)
+  params = eng.load_params(params=weights)
+  rng = np.random.default_rng(4096)
+  toks = torch.from_numpy(rng.integers(1, cfg.vocab_size, size=total).astype(np.int32)).to(eng.device)
+
+  def run():
+    done, pre = 0, None
+    while done < total:
+      n = min(P, total - done)
+      ep = None if done == 0 else maxengine.ExistingPrefix(cache=pre["cache"], common_prefix_tokens=toks[:done])
+      pre, _ = eng.prefill(params=params, padded_tokens=toks[done:done + n], true_length=n, slot=0, existing_prefix=ep)
+      done += n
+    torch.cuda.synchronize()
+    eng.release_pages(0)
+  run()
+  t0 = time.perf_counter()
+  run()
+  dt = time.perf_counter() - t0
+  del eng
+  flops = 2.0 * total * nums["body_params"] + 4.0 * 16 * 128 * 16 * total * total / 2 + (total // P) * 2.0 * nums["unembed_params"]
+  return {"prompt_tokens": total, "chunk": P, "seconds": dt, "prefill_tokens_per_s": total / dt, "mfu": flops / dt / MFMA_BF16_PEAK}
 
 
 def cpu_baseline(args, cfg, weights, prompts):
