@@ -88,7 +88,8 @@ struct ixt_ctx {
   // MLP down-projection on the ring path: 1 = ring GEMM with the residual epilogue; 0 = split-K tiles (one f32 slice per 512-k chain, two blocks
   // per CU) + slice-sum / residual / norm kernel; -1 (default) = by shape: the ring form needs at least 192 whole-K blocks of 128 x 128 or 128 x 64
   int ring_down = -1;
-  int unembed_tall = 1;   // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
+  int unembed_tall = 1;      // 256 x 128 tiles for the unembedding at 129..256 rows (0: 128 x 128)
+  int ring_two_per_cu = 1;   // ring GEMMs of >= 1024 rows: 32-k chunks in 4 slots (64 KiB of LDS), two blocks per CU
   int attn_tile = 1;         // prefill rows: tiled attention (k_attn_tile) from attn_tile_min_rows rows on
   int attn_tile_min_rows = 64;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
@@ -546,7 +547,18 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
 #define RING_B(EPI_) ring_launch_t<2, 4, 4, 1, 2, 5, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
 #define RING_C(EPI_) ring_launch_t<2, 2, 2, 1, 4, 6, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
 #define RING(EPI_) do { if (cfg == 1) rc = RING_A(EPI_, 0); else if (cfg == 2) rc = RING_B(EPI_); else rc = RING_C(EPI_); } while (0)
-  if (epi == GEPI_F32 && split) rc = RING_A(GEPI_F32, 1);
+  // Prefill-sized launches (several rounds of blocks per CU): the 128 x 128 tile with 32-k chunks in 4 slots = 64 KiB of LDS, so TWO blocks
+  // share a CU and one's prologue (first chunk's latency) and epilogue run under the other's main loop: 7.6 -> 6.7 ms of GEMMs per 2048-row
+  // pass.  At 256 rows a launch has at most one block per CU anyway and the 64-k chunks (half the barriers) are faster.
+#define RING_P(EPI_) ring_launch_t<2, 4, 4, 2, 1, 4, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
+  const bool two_per_cu = c->ring_two_per_cu && R >= 1024 && cfg == 1 && !split;
+  if (two_per_cu && epi == GEPI_RESID && (long)((N + 127) / 128) * ((R + 127) / 128) < 512)   // O / MLP down at 2048 rows: 256 such tiles; 128 x 64 tiles
+    rc = ring_launch_t<2, 4, 4, 1, 2, 3, GEPI_RESID, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);   // (72 KiB of LDS) give every CU its two blocks
+  else if (two_per_cu && epi == GEPI_RESID) rc = RING_P(GEPI_RESID);
+  else if (two_per_cu && epi == GEPI_QKV) rc = RING_P(GEPI_QKV);
+  else if (two_per_cu && epi == GEPI_SWIGLU) rc = RING_P(GEPI_SWIGLU);
+  else if (two_per_cu && epi == GEPI_F32) rc = RING_P(GEPI_F32);
+  else if (epi == GEPI_F32 && split) rc = RING_A(GEPI_F32, 1);
   else if (epi == GEPI_F32) RING(GEPI_F32);
   else if (epi == GEPI_RESID) RING(GEPI_RESID);
   else if (epi == GEPI_QKV) RING(GEPI_QKV);
@@ -564,6 +576,7 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
 #undef RING_A
 #undef RING_B
 #undef RING_C
+#undef RING_P
   timing_end(c, st, ti);
   if (rc == IXT_ERR_UNSUPPORTED) return set_err(rc, "ring gemm: epilogue %d", epi);
   return rc;
@@ -1286,7 +1299,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"attn_fused_min_blocks", &c->attn_fused_min_blocks, 1}, {"gemm_prefix_halves", &c->gemm_prefix_halves, 0},
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
-      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0},
+      {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;
