@@ -551,10 +551,10 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   // share a CU and one's prologue (first chunk's latency) and epilogue run under the other's main loop: 7.6 -> 6.7 ms of GEMMs per 2048-row
   // pass.  At 256 rows a launch has at most one block per CU anyway and the 64-k chunks (half the barriers) are faster.
 #define RING_P(EPI_) ring_launch_t<2, 4, 4, 2, 1, 4, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
-  const bool two_per_cu = c->ring_two_per_cu && R >= 1024 && cfg == 1 && !split;
-  if (two_per_cu && epi == GEPI_RESID && (long)((N + 127) / 128) * ((R + 127) / 128) < 512)   // O / MLP down at 2048 rows: 256 such tiles; 128 x 64 tiles
-    rc = ring_launch_t<2, 4, 4, 1, 2, 3, GEPI_RESID, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols);   // (72 KiB of LDS) give every CU its two blocks
-  else if (two_per_cu && epi == GEPI_RESID) rc = RING_P(GEPI_RESID);
+  // (O / MLP down at 2048 rows are 256 tiles: one block per CU either way, and there the 64-k chunks win -- 8.5 against 8.7 ms per pass with 512 tiles
+  // of 128 x 64 in 72 KiB)
+  const bool two_per_cu = c->ring_two_per_cu && R >= 1024 && cfg == 1 && !split && (long)((N + 127) / 128) * ((R + 127) / 128) >= 512;
+  if (two_per_cu && epi == GEPI_RESID) rc = RING_P(GEPI_RESID);
   else if (two_per_cu && epi == GEPI_QKV) rc = RING_P(GEPI_QKV);
   else if (two_per_cu && epi == GEPI_SWIGLU) rc = RING_P(GEPI_SWIGLU);
   else if (two_per_cu && epi == GEPI_F32) rc = RING_P(GEPI_F32);
