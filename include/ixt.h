@@ -212,8 +212,8 @@ int ixt_set_sampling_ranges(ixt_ctx* ctx, const int32_t* lo_hi, int nranges);
  *   "attn_tile"              1 (default): prefill calls of at least "attn_tile_min_rows" rows (default 64) run the tiled attention: 16 (8 past
  *                            ~1500 keys) consecutive rows per block share every K / V load; 0: one block per (row, kv head) as for decode rows
  *   "unembed_tall"           1 (default): the unembedding at 129..256 rows uses 256 x 128 tiles (weights enter the chip once); 0: 128 x 128
- *   "ring_two_per_cu"        1 (default): ring GEMMs of 1024 rows and more use 32-k chunks in 4 slots (64 KiB of LDS: two blocks per CU overlap
- *                            each other's prologue and epilogue); 0: the 64-k chunk form of the 256-row launches
+ *   "ring_two_per_cu"        1 (default): ring GEMMs (and the unembedding) of 1024 rows and more with at least 320 tiles of 128 x 128 use 32-k chunks
+ *                            in 4 slots (64 KiB of LDS: two blocks per CU overlap each other's prologue and epilogue); 0: the 64-k chunk form
  *   "ring_down"              MLP down-projection on the ring path: 1 ring GEMM + residual epilogue, 0 split-K tiles + slice-sum kernel,
  *                            -1 (default) by shape */
 int ixt_set_option(ixt_ctx* ctx, const char* name, int value);

@@ -215,6 +215,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   PageStateDev& s = x->ps;
   s.num_pages = c.pagedattn_num_pages; s.groups = x->G; s.decode_groups = x->B; s.mpg = x->mpg; s.P = x->P;
   A(dmalloc(x, &s.status, (size_t)4));
+  A(dmalloc(x, &s.meta, (size_t)2));
   A(dmalloc(x, &s.page_status, (size_t)s.num_pages));
   A(dmalloc(x, &s.page_map, (size_t)s.groups * s.mpg));
   A(dmalloc(x, &s.num_pages_used, (size_t)s.groups));
@@ -474,6 +475,8 @@ extern "C" int ixt_pages_import_status(ixt_ctx* c, const int32_t* page_status, v
   if (!c || !page_status) return set_err(IXT_ERR_INVALID, "null argument");
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));
   HIPCHK(hipMemcpy(c->ps.page_status, page_status, sizeof(int32_t) * c->ps.num_pages, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_pages_recount, dim3(1), dim3(64), 0, (hipStream_t)stream, c->ps);
+  LAUNCHCHK();
   return IXT_OK;
 }
 
@@ -551,9 +554,9 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   // share a CU and one's prologue (first chunk's latency) and epilogue run under the other's main loop: 7.6 -> 6.7 ms of GEMMs per 2048-row
   // pass.  At 256 rows a launch has at most one block per CU anyway and the 64-k chunks (half the barriers) are faster.
 #define RING_P(EPI_) ring_launch_t<2, 4, 4, 2, 1, 4, EPI_, 0>(x, w, K, N, R, chains, wring, e, st, wave_cols)
-  // (O / MLP down at 2048 rows are 256 tiles: one block per CU either way, and there the 64-k chunks win -- 8.5 against 8.7 ms per pass with 512 tiles
-  // of 128 x 64 in 72 KiB)
-  const bool two_per_cu = c->ring_two_per_cu && R >= 1024 && cfg == 1 && !split && (long)((N + 127) / 128) * ((R + 127) / 128) >= 512;
+  // (launches of up to 256 tiles -- O / MLP down at 2048 rows -- have one block per CU either way, and there the 64-k chunks win: 8.5 against 8.7 ms
+  // per pass with 512 tiles of 128 x 64 in 72 KiB; from 384 tiles on -- QKV at 1024 rows -- the two-per-CU form wins)
+  const bool two_per_cu = c->ring_two_per_cu && R >= 1024 && cfg == 1 && !split && (long)((N + 127) / 128) * ((R + 127) / 128) >= 320;
   if (two_per_cu && epi == GEPI_RESID) rc = RING_P(GEPI_RESID);
   else if (two_per_cu && epi == GEPI_QKV) rc = RING_P(GEPI_QKV);
   else if (two_per_cu && epi == GEPI_SWIGLU) rc = RING_P(GEPI_SWIGLU);
@@ -562,6 +565,7 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
   else if (epi == GEPI_F32) RING(GEPI_F32);
   else if (epi == GEPI_RESID) RING(GEPI_RESID);
   else if (epi == GEPI_QKV) RING(GEPI_QKV);
+  else if (two_per_cu && epi == GEPI_UNEMBED) rc = RING_P(GEPI_UNEMBED);
   else if (epi == GEPI_UNEMBED) {
     // the unembedding at 129..256 rows: ONE block owns all rows of its 128 columns (8 waves of 64 x 64: 256 x 128 tile, 3 slots of 48 KiB), so the
     // 1 GB kernel enters the chip once instead of once per 128-row group

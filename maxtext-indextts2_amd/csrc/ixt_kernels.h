@@ -1968,42 +1968,32 @@ struct PageStateDev {
   int32_t* active_page;          // [groups]
   int32_t* has_active_page;      // [groups] (0/1)
   int32_t* active_page_position; // [groups]
-  int32_t* status;               // [4] build extension: {failed reservations, last group that failed, decode rows left without a page, 0}
+  int32_t* status;               // [4] build extension: {failed reservations, last group that failed, decode rows left without a page, packed rows beyond max_len}
+  int32_t* meta;                 // [2] bookkeeping of page_status, kept by every kernel that changes it: {free pages, an index below which no page is free}
   int num_pages, groups, mpg, P; // groups = decode slots + staging groups of packed prefill (build extension)
   int decode_groups;             // the reference's page groups (slots); only these advance in update_decode_pages
 };
 
-// lowest index >= 1 with status 0, else -1 (page_manager.py:129-156); whole wave cooperates.
 // Every access is an agent-scope (L1-bypassing) access followed by a wave-level drain, because the
 // same wave re-reads words that its lane 0 has just written.
 __device__ __forceinline__ void wave_drain() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-__device__ int wave_find_free(const int32_t* status, int num_pages, int lane) {
-  for (int base = 0; base < num_pages; base += 64) {
-    const int i = base + lane;
-    const bool free_ = (i >= 1 && i < num_pages) ? (ldg_i32(status + i) == 0) : false;
-    const unsigned long long mask = __ballot(free_);
-    if (mask) return base + __ffsll((long long)mask) - 1;
-  }
-  return -1;
-}
-__device__ int wave_count_free(const int32_t* status, int num_pages, int lane) {
-  int c = 0;
-  for (int base = 0; base < num_pages; base += 64) {
-    const int i = base + lane;
-    const bool free_ = i < num_pages ? (ldg_i32(status + i) == 0) : false;
-    c += __popcll(__ballot(free_));
-  }
-  return c;
-}
-
 __device__ void wave_release_group(PageStateDev s, int g, int lane) {
   const int nvalid = ldg_i32(s.num_pages_used + g);
+  int nrel = 0, lowest = 0x7fffffff;
   for (int i = lane; i < s.mpg; i += 64) {
     const int idx = ldg_i32(s.page_map + (size_t)g * s.mpg + i);
-    if (i < nvalid && idx > 0) stg_i32(s.page_status + idx, 0);
+    if (i < nvalid && idx > 0) {
+      if (ldg_i32(s.page_status + idx) != 0) ++nrel;     // (a page listed twice is counted once)
+      stg_i32(s.page_status + idx, 0);
+      lowest = min(lowest, idx);
+    }
   }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { nrel += __shfl_xor(nrel, off, 64); lowest = min(lowest, __shfl_xor(lowest, off, 64)); }
   if (lane == 0) {
+    stg_i32(s.meta + 0, ldg_i32(s.meta + 0) + nrel);
+    if (lowest < ldg_i32(s.meta + 1)) stg_i32(s.meta + 1, lowest);
     stg_i32(s.num_pages_used + g, 0); stg_i32(s.sequence_lengths + g, 0); stg_i32(s.active_page + g, 0);
     stg_i32(s.has_active_page + g, 0); stg_i32(s.active_page_position + g, 0);
   }
@@ -2019,6 +2009,17 @@ __global__ __launch_bounds__(64) void k_pages_reset(PageStateDev s) {
     s.has_active_page[i] = 0; s.active_page_position[i] = 0;
   }
   if (lane < 4) s.status[lane] = 0;
+  if (lane == 0) { s.meta[0] = s.num_pages - 1; s.meta[1] = 1; }
+}
+// page_status written from outside (tests): count the free pages and find the lowest one again
+__global__ __launch_bounds__(64) void k_pages_recount(PageStateDev s) {
+  const int lane = threadIdx.x;
+  int c = 0, lowest = s.num_pages;
+  for (int i = 1 + lane; i < s.num_pages; i += 64)
+    if (s.page_status[i] == 0) { ++c; lowest = min(lowest, i); }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { c += __shfl_xor(c, off, 64); lowest = min(lowest, __shfl_xor(lowest, off, 64)); }
+  if (lane == 0) { s.meta[0] = c; s.meta[1] = lowest; }
 }
 __global__ __launch_bounds__(64) void k_pages_release(PageStateDev s, int g) { wave_release_group(s, g, threadIdx.x); }
 
@@ -2026,9 +2027,16 @@ __global__ __launch_bounds__(64) void k_pages_release(PageStateDev s, int g) { w
 // Sequential first-fit (page_manager.py:268-283, :373-395: "next free page" for one request after the other, nothing freed in
 // between) hands out exactly these pages in exactly this order, so one scan serves a whole batch of requests.
 // Plain loads: within one launch every status word is read before this wave may write it.
-__device__ int wave_take_free(int32_t* status, int num_pages, int lane, int m, int32_t* out) {
-  int cnt = 0;
-  for (int base = 0; base < num_pages && cnt < m; base += 512) {
+// The scan starts at meta[1] (no page below it is free: releases lower it, and the m lowest free pages having been taken, everything up to
+// the last of them is in use) and meta[0] counts the free pages -- the pool of a 1024-slot engine has 41 000 status words, and a scan from
+// index 0 per reservation cost 117 us.
+__device__ int wave_take_free(PageStateDev s, int lane, int m, int32_t* out) {
+  int32_t* status = s.page_status;
+  const int num_pages = s.num_pages;
+  int cnt = 0, last = -1;
+  if (m <= 0) return 0;
+  const int hint = ldg_i32(s.meta + 1);
+  for (int base = (hint / 512) * 512; base < num_pages && cnt < m; base += 512) {
     int v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -2042,26 +2050,19 @@ __device__ int wave_take_free(int32_t* status, int num_pages, int lane, int m, i
       const unsigned long long mask = __ballot(free_);
       if (free_) {
         const int rank = cnt + __popcll(mask & ((1ull << lane) - 1ull));
-        if (rank < m) { out[rank] = i; status[i] = 1; }
+        if (rank < m) { out[rank] = i; status[i] = 1; last = max(last, i); }
       }
       cnt += __popcll(mask);
     }
   }
-  return cnt < m ? cnt : m;
-}
-__device__ int wave_count_free8(const int32_t* status, int num_pages, int lane) {
-  int c = 0;
-  for (int base = 0; base < num_pages; base += 512) {
-    int v[8];
+  const int found = cnt < m ? cnt : m;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int i = base + u * 64 + lane;
-      v[u] = i < num_pages ? status[i] : 1;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) c += __popcll(__ballot(v[u] == 0));
+  for (int off = 1; off < 64; off <<= 1) last = max(last, __shfl_xor(last, off, 64));
+  if (lane == 0) {
+    stg_i32(s.meta + 0, ldg_i32(s.meta + 0) - found);
+    stg_i32(s.meta + 1, found < m ? num_pages : last + 1);      // fewer than asked for: the pool is exhausted from here on
   }
-  return c;
+  return found;
 }
 #define IXT_MAX_GROUPS 4096
 
@@ -2077,12 +2078,12 @@ __global__ __launch_bounds__(64) void k_pages_reserve(PageStateDev s, int g, int
   const int need = (length + s.P - 1) / s.P;
   const int have = extend ? ldg_i32(s.num_pages_used + g) : 0;
   const int extra = need > have ? need - have : 0;
-  const int nfree = wave_count_free8(s.page_status, s.num_pages, lane);
+  const int nfree = ldg_i32(s.meta + 0);
   if (!(nfree >= extra && need <= s.mpg)) {   // the reference returns the released state silently (page_manager.py:305-311); recorded here
     if (lane == 0) { s.status[0] = s.status[0] + 1; s.status[1] = g; }
     return;
   }
-  const int found = wave_take_free(s.page_status, s.num_pages, lane, extra, got);
+  const int found = wave_take_free(s, lane, extra, got);
   __syncthreads();
   for (int k = lane; k < found; k += 64) s.page_map[(size_t)g * s.mpg + have + k] = got[k];
   __syncthreads();
@@ -2119,7 +2120,7 @@ __global__ __launch_bounds__(64) void k_pages_advance(PageStateDev s) {
   }
   if (m == 0) return;
   __syncthreads();
-  const int found = wave_take_free(s.page_status, s.num_pages, lane, m, got);
+  const int found = wave_take_free(s, lane, m, got);
   __syncthreads();
   if (lane == 0 && found < m) s.status[2] = s.status[2] + (m - found);   // these rows stay idle (k_rows_decode) until a page is free
   for (int k = lane; k < found; k += 64) {

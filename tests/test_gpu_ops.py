@@ -285,11 +285,12 @@ def test_kv_write_attention(ctx):
   assert not np.any(got[-1])  # inactive row attends to nothing
 
 
-@pytest.mark.parametrize("R", [3, 130])
+@pytest.mark.parametrize("R", [3, 130, 300, 1024])
 def test_unembed_argmax_ties(ctx, R):
   """First-index tie break (jnp.argmax, inference_utils.py:74-75): the maximum of every row is made to occur at several columns by
   copying the winning weight column into columns on both sides of it -- in the same 16-column tile, in another tile of the same
-  wave, and in another block -- and the FIRST of them must win."""
+  wave, and in another block -- and the FIRST of them must win.  3 rows: the small-batch kernel; 130: the 256 x 128 ring tile; 300 and 1024 (the
+  bench's decode batch): 128 x 128 ring tiles, several row groups per column tile."""
   torch, eng, O, cfg = ctx["torch"], ctx["eng"], ctx["O"], ctx["cfg"]
   rng = np.random.default_rng(5)
   E, V = cfg.emb_dim, cfg.vocab_size
@@ -309,7 +310,7 @@ def test_unembed_argmax_ties(ctx, R):
   # load the tied kernel into a private engine (the module fixture keeps its own weights)
   wt = dict(ctx["w"])
   wt["params/decoder/logits_dense/kernel"] = w
-  eng2, _ = H.make_engine(H.make_config(per_device_batch_size=136.0, pagedattn_num_pages=256), wt)
+  eng2, _ = H.make_engine(H.make_config(per_device_batch_size=float(max(136, R)), pagedattn_num_pages=256), wt)
   logits = torch.empty((R, V), dtype=torch.float32, device="cuda")
   amax = torch.empty((R,), dtype=torch.int32, device="cuda")
   yd = H.dev_bf16(y)
