@@ -319,3 +319,33 @@ def test_unembed_argmax_ties(ctx, R):
   assert np.array_equal(got.view(np.uint32), lg.view(np.uint32))
   assert np.array_equal(amax.cpu().numpy(), np.argmax(lg, axis=-1).astype(np.int32))
   assert int(amax[0]) == dup[0]
+
+
+@pytest.mark.parametrize("R", [1024, 1100])
+def test_unembed_two_blocks_per_cu_form(ctx, R):
+  """The unembedding as the bench's decode step runs it at 1024 utterances: >= 1024 rows and >= 320 tiles of 128 x 128 select the ring GEMM's
+  two-blocks-per-CU form (32-k chunks in 4 slots) with the sampling epilogue; rounded logits and first-index argmax against the oracle's dot
+  (vocabulary 6144: 48 column tiles x 8 or 9 row groups; 1100: a ragged last row group)."""
+  torch, O = ctx["torch"], ctx["O"]
+  cfg = H.make_config(per_device_batch_size=float(R), pagedattn_num_pages=256, vocab_size=6144)
+  w = H.synth.synth_weights(cfg, 3)
+  eng, _ = H.make_engine(cfg, w)
+  E, V = cfg.emb_dim, cfg.vocab_size
+  rng = np.random.default_rng(R)
+  y = H.rand_bf16(rng, (R, E))
+  lg = np.zeros((R, V), np.float32)
+  wl = w["params/decoder/logits_dense/kernel"].reshape(E, V)
+  O.lib().orc_dot_rows(O._p(y, O._u16p), E, R, O._p(wl, O._u16p), E, V, O._p(lg, O._f32p), V)
+  lg = O.bf16_to_f32(O.f32_to_bf16(lg)).reshape(R, V)
+  logits = torch.empty((R, V), dtype=torch.float32, device="cuda")
+  amax = torch.empty((R,), dtype=torch.int32, device="cuda")
+  yd = H.dev_bf16(y)
+  H.lib.check(eng.lib.ixt_op_unembed_argmax(eng._ctx, _vp(yd), R, _vp(logits), _vp(amax), _st(torch)))
+  assert np.array_equal(logits.cpu().numpy().view(np.uint32), lg.view(np.uint32))
+  assert np.array_equal(amax.cpu().numpy(), np.argmax(lg, axis=-1).astype(np.int32))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_two_per_cu", 0))      # and the 64-k chunk form gives the same bits
+  logits2 = torch.empty_like(logits)
+  H.lib.check(eng.lib.ixt_op_unembed_argmax(eng._ctx, _vp(yd), R, _vp(logits2), _vp(amax), _st(torch)))
+  assert torch.equal(logits, logits2)
+  del eng
+  torch.cuda.synchronize()
