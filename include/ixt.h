@@ -170,6 +170,10 @@ int ixt_op_paged_attention(ixt_ctx* ctx, int layer, const uint16_t* q, const int
 /* Decoder._apply_output_head logits + greedy sampling (decoders.py:566-587, inference_utils.py:74-75):
  * y bf16[R][emb] (already normed) -> logits f32[R][vocab] (may be NULL), argmax int32[R]. */
 int ixt_op_unembed_argmax(ixt_ctx* ctx, const uint16_t* y, int R, float* logits, int32_t* argmax, void* stream);
+/* inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63; the engine's return_log_prob outputs, maxengine.py:502-516, 907-926):
+ * logits f32[rows][vocab] (the rounded logits ixt_prefill_chunk / ixt_generate / ixt_op_unembed_argmax write), chosen int32[rows] ->
+ * out f32[rows] = log_softmax(logits[r])[chosen[r]]. */
+int ixt_op_logprob(ixt_ctx* ctx, const float* logits_dev, int rows, const int32_t* chosen_dev, float* out_dev, void* stream);
 /* Gather a slot's K and V of one layer to dense bf16[length][nkv][hd] device arrays (cache export). */
 int ixt_kv_gather(ixt_ctx* ctx, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream);
 /* RoPE tables (bf16 bit patterns) to HOST arrays [max_target_length][head_dim/2]. */

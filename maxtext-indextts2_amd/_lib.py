@@ -52,6 +52,7 @@ SIGNATURES = {
     "ixt_pages_status": (ctypes.c_int, [vp, c_i32p, ctypes.c_int, vp]),
     "ixt_build_id": (ctypes.c_char_p, []),
     "ixt_prefill_rows": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),
+    "ixt_op_logprob": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
     "ixt_pages_export": (ctypes.c_int, [vp, c_i32p, c_i32p, c_i32p, c_i32p, c_i32p, c_u8p, c_i32p, vp]),
     "ixt_pages_import_status": (ctypes.c_int, [vp, c_i32p, vp]),
     "ixt_prefill_chunk": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp]),

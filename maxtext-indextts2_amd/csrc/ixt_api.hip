@@ -471,6 +471,15 @@ extern "C" int ixt_pages_export(ixt_ctx* c, int32_t* page_status, int32_t* page_
   }
   return IXT_OK;
 }
+extern "C" int ixt_op_logprob(ixt_ctx* c, const float* logits_dev, int rows, const int32_t* chosen_dev, float* out_dev, void* stream) {
+  if (!c || !logits_dev || !chosen_dev || !out_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  if (rows <= 0) return set_err(IXT_ERR_RANGE, "log-prob of %d rows", rows);
+  const int nblk = (c->V + 1023) / 1024;
+  hipLaunchKernelGGL(k_logprob, dim3(rows), dim3(256), sizeof(float) * nblk, (hipStream_t)stream, logits_dev, c->V, chosen_dev, out_dev);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
 extern "C" int ixt_pages_import_status(ixt_ctx* c, const int32_t* page_status, void* stream) {
   if (!c || !page_status) return set_err(IXT_ERR_INVALID, "null argument");
   HIPCHK(hipStreamSynchronize((hipStream_t)stream));

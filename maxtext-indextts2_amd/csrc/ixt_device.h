@@ -46,6 +46,26 @@ __device__ __forceinline__ float ixt_exp(float x) {
   return p * s;
 }
 
+// natural logarithm from IEEE-only operations (positive normal arguments): x = 2^e f, f in [sqrt(1/2), sqrt(2)); z = (f - 1) / (f + 1);
+// log f = 2 z (1 + z^2/3 + ... + z^10/11) by Horner fma; result = fma(e, ln2_hi, fma(e, ln2_lo, log f)).
+__device__ __forceinline__ float ixt_log(float x) {
+  const uint32_t u = __float_as_uint(x);
+  int e = (int)(u >> 23) - 127;
+  float f = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+  if (f > 1.41421356237309504880f) { f = f * 0.5f; e = e + 1; }
+  const float z = (f - 1.0f) / (f + 1.0f);
+  const float w = z * z;
+  float p = 9.09090909090909090909e-2f;
+  p = __builtin_fmaf(p, w, 1.11111111111111111111e-1f);
+  p = __builtin_fmaf(p, w, 1.42857142857142857143e-1f);
+  p = __builtin_fmaf(p, w, 0.2f);
+  p = __builtin_fmaf(p, w, 3.33333333333333333333e-1f);
+  p = __builtin_fmaf(p, w, 1.0f);
+  const float lf = (z + z) * p;
+  const float fe = (float)e;
+  return __builtin_fmaf(fe, 0.693145751953125f, __builtin_fmaf(fe, 1.42860682030941723212e-6f, lf));
+}
+
 // MlpBlock gate: bf16(bf16(a * bf16(sigmoid(a))) * b)
 __device__ __forceinline__ bf16_t ixt_swiglu(float a, float b) {
   float sg = rbf(1.0f / (1.0f + ixt_exp(-a)));

@@ -1891,6 +1891,37 @@ __global__ __launch_bounds__(256) void k_attn_combine(const float* pvpart, const
 }
 
 // =====================================================================================================
+// inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63) on rows of f32 logits: (x[chosen] - max) - log(sum exp(x - max)); the sum
+// in blocks of 1024 consecutive columns (one thread each, left to right), block sums added left to right.  grid = rows, block 256.
+// =====================================================================================================
+__global__ __launch_bounds__(256) void k_logprob(const float* __restrict__ logits, int vocab, const int32_t* __restrict__ chosen, float* __restrict__ out) {
+  extern __shared__ float lp_sm[];              // [ceil(vocab / 1024)] block sums
+  __shared__ float wred[4];
+  const int r = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const float* row = logits + (size_t)r * vocab;
+  float m = -INFINITY;
+  for (int n = tid; n < vocab; n += 256) m = fmaxf(m, row[n]);
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  if (lane == 0) wred[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
+  const int nblk = (vocab + 1023) / 1024;
+  for (int b = tid; b < nblk; b += 256) {
+    float s = 0.0f;
+    const int n1 = min(vocab, (b + 1) * 1024);
+    for (int n = b * 1024; n < n1; ++n) s = s + ixt_exp(row[n] - m);
+    lp_sm[b] = s;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float total = 0.0f;
+    for (int b = 0; b < nblk; ++b) total = total + lp_sm[b];
+    out[r] = (row[chosen[r]] - m) - ixt_log(total);
+  }
+}
+
+// =====================================================================================================
 // RoPE on dense rows (op-level).  grid = (R, nheads), block = hd/2.
 // =====================================================================================================
 __global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, const bf16_t* rope_cos, int nheads, int hd) {

@@ -163,6 +163,15 @@ class MaxEngine(engine_api.Engine):
       mapping = AudioTokenMapping.from_npz(path) if path.endswith(".npz") else AudioTokenMapping.from_json(path)
     self.set_sampling_ranges(mapping.audio_row_ranges())
 
+  def _token_logp(self, logits: torch.Tensor, tokens: torch.Tensor) -> torch.Tensor:
+    """inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63) of `tokens` [n, 1] under `logits` [n, ..., V]: f32 [n, 1]."""
+    n = tokens.shape[0]
+    out = torch.empty((n, 1), dtype=torch.float32, device=self.device)
+    tok = tokens.reshape(n).to(torch.int32).contiguous()
+    _lib.check(self.lib.ixt_op_logprob(self._ctx, ctypes.c_void_p(logits.data_ptr()), n, ctypes.c_void_p(tok.data_ptr()), ctypes.c_void_p(out.data_ptr()),
+                                       ctypes.c_void_p(_stream_ptr())))
+    return out
+
   # ------------------------------------------------------------------ prefill
   def prefill(self, *, params: Params, existing_prefix: Optional[ExistingPrefix] = None, padded_tokens: Any, images: Any = None,
               true_length: int, sampler: Any = None, rng: Any = None, request_id: Any = None, slot: Optional[int] = None,
@@ -171,8 +180,8 @@ class MaxEngine(engine_api.Engine):
     del params, sampler, rng, request_id
     if images is not None:
       raise NotImplementedError("multimodal prefill is outside the built path")
-    if return_prompt_logp or self.config.return_log_prob:
-      raise NotImplementedError("log-prob outputs are outside the built path")
+    if return_prompt_logp:
+      raise NotImplementedError("return_prompt_logp needs the logits of every prompt row; only the last row's are computed here")
     if slot is None:
       slot = 0
     true_length = int(true_length)
@@ -196,7 +205,8 @@ class MaxEngine(engine_api.Engine):
                                           ctypes.c_void_p(first.data_ptr()), ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
     generated = torch.zeros((1, 1), dtype=torch.int32, device=self.device)
     data = torch.cat([first, torch.ones_like(first), generated], dim=1)
-    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=1)
+    token_logp = self._token_logp(logits, first) if self.config.return_log_prob else None     # maxengine.py:502-505
+    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=token_logp, samples_per_slot=1)
     next_pos = torch.full((1, 1), start + true_length, dtype=torch.int32, device=self.device)
     prefix = {
         "logits": logits,
@@ -216,11 +226,12 @@ class MaxEngine(engine_api.Engine):
     num_samples = int(num_samples)
     if num_samples < 1:
       raise ValueError(f"num_samples ({num_samples}) must be at least 1")
-    prefix, _ = self.prefill(params=params, padded_tokens=padded_tokens, true_length=true_length, sampler=sampler, rng=rng, slot=slot)
+    prefix, res1 = self.prefill(params=params, padded_tokens=padded_tokens, true_length=true_length, sampler=sampler, rng=rng, slot=slot)
     first = prefix["tokens"].expand(num_samples, 1).contiguous()
     generated = torch.zeros((num_samples, 1), dtype=torch.int32, device=self.device)
     data = torch.cat([first, torch.ones_like(first), generated], dim=1)
-    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=num_samples)
+    logp = res1.log_prob.expand(num_samples, 1).contiguous() if res1.log_prob is not None else None      # maxengine.py:684-689
+    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=logp, samples_per_slot=num_samples)
     prefix = dict(prefix, tokens=first, generated_tokens=generated)
     return prefix, result
 
@@ -235,8 +246,8 @@ class MaxEngine(engine_api.Engine):
     del params, sampler, rng, decoder_segment_ids
     if existing_prefix:
       raise ValueError("We don't know what to do with existing_prefix")
-    if return_prompt_logp or self.config.return_log_prob:
-      raise NotImplementedError("log-prob outputs are outside the built path")
+    if return_prompt_logp:
+      raise NotImplementedError("return_prompt_logp needs the logits of every prompt row; only the last rows' are computed here")
     n = int(num_prompts)
     if n <= 0 or n > self._staging:
       raise ValueError(f"prefill_concat: num_prompts ({n}) out of range (0, ixt_staging_groups={self._staging}]")
@@ -270,9 +281,11 @@ class MaxEngine(engine_api.Engine):
     generated = torch.zeros((n, 1, 1), dtype=torch.int32, device=self.device)
     tokens = first.reshape(n, 1, 1)
     results = []
+    logps = self._token_logp(logits, first.reshape(n, 1)) if self.config.return_log_prob else None     # maxengine.py:801-804
     for i in range(n):
       data = torch.cat([tokens[i], torch.ones_like(tokens[i]), generated[i]], dim=1)
-      results.append(engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None, samples_per_slot=1))
+      results.append(engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3),
+                                             log_prob=logps[i:i + 1] if logps is not None else None, samples_per_slot=1))
     prefill_results = {"logits": logits, "next_pos": next_pos, "generated_tokens": generated, "tokens": tokens, "prompt_logp": None}
     cache = PagedCacheHandle(self, None, 0, groups=[B + i for i in range(n)], lengths=lens)
     return cache, prefill_results, results
@@ -282,13 +295,17 @@ class MaxEngine(engine_api.Engine):
     """maxengine.py:838-936: page advance + one token for all slots + state update, in one library call."""
     del params, sampler, rng
     lg = decode_state.get("logits")
+    if self.config.return_log_prob and not isinstance(lg, torch.Tensor):     # the log-probabilities are taken from the step's rounded logits
+      lg = torch.empty((self._B, 1, self.config.vocab_size), dtype=torch.float32, device=self.device)
+      decode_state["logits"] = lg
     lg_ptr = ctypes.c_void_p(lg.data_ptr()) if isinstance(lg, torch.Tensor) else None
     _lib.check(self.lib.ixt_generate(self._ctx, ctypes.c_void_p(decode_state["tokens"].data_ptr()),
                                      ctypes.c_void_p(decode_state["next_pos"].data_ptr()),
                                      ctypes.c_void_p(decode_state["generated_tokens"].data_ptr()),
                                      ctypes.c_void_p(self._result.data_ptr()), lg_ptr, ctypes.c_void_p(_stream_ptr())))
-    result = engine_api.ResultTokens(data=self._result.clone(), tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=None,
-                                     samples_per_slot=1)
+    data = self._result.clone()
+    token_logp = self._token_logp(lg, data[:, 0:1]) if self.config.return_log_prob else None   # maxengine.py:907-910 (idle slots: of their stale logits)
+    result = engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3), log_prob=token_logp, samples_per_slot=1)
     return decode_state, result
 
   # ------------------------------------------------------------------ insert

@@ -105,6 +105,54 @@ float orc_exp(float x) {
   return p * s;
 }
 
+/* natural logarithm in IEEE-only operations, identical op sequence to the device implementation (ixt_log): x = 2^e f with f in
+ * [sqrt(1/2), sqrt(2)); z = (f - 1) / (f + 1); log f = 2 z (1 + z^2/3 + z^4/5 + z^6/7 + z^8/9 + z^10/11) by Horner fma in z^2
+ * (|z| <= 0.1716: the next term is below 2e-11 relative); result = fma(e, ln2_hi, fma(e, ln2_lo, log f)).  Positive normal x only. */
+float orc_log(float x) {
+  uint32_t u;
+  memcpy(&u, &x, 4);
+  int32_t e = (int32_t)(u >> 23) - 127;
+  uint32_t mb = (u & 0x007fffffu) | 0x3f800000u;
+  float f;
+  memcpy(&f, &mb, 4);                                   /* [1, 2) */
+  if (f > 1.41421356237309504880f) { f = f * 0.5f; e = e + 1; }
+  float z = (f - 1.0f) / (f + 1.0f);
+  float w = z * z;
+  float p = 9.09090909090909090909e-2f;                 /* 1/11 */
+  p = fmaf(p, w, 1.11111111111111111111e-1f);           /* 1/9 */
+  p = fmaf(p, w, 1.42857142857142857143e-1f);           /* 1/7 */
+  p = fmaf(p, w, 0.2f);
+  p = fmaf(p, w, 3.33333333333333333333e-1f);           /* 1/3 */
+  p = fmaf(p, w, 1.0f);
+  float lf = (z + z) * p;
+  float fe = (float)e;
+  return fmaf(fe, 0.693145751953125f, fmaf(fe, 1.42860682030941723212e-6f, lf));
+}
+
+/* inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63) on one row of f32 logits: jax.nn.log_softmax = shifted - log(sum(exp(
+ * shifted))), shifted = x - max.  Canonical order of the sum: blocks of 1024 consecutive columns summed left to right from 0, block sums
+ * added left to right from 0 (exp = orc_exp). */
+float orc_logprob_row(const float* row, int vocab, int chosen) {
+  float m = -INFINITY;
+  for (int n = 0; n < vocab; ++n)
+    if (row[n] > m) m = row[n];
+  float total = 0.0f;
+  for (int b = 0; b < vocab; b += 1024) {
+    float s = 0.0f;
+    int n1 = b + 1024 < vocab ? b + 1024 : vocab;
+    for (int n = b; n < n1; ++n) s = s + orc_exp(row[n] - m);
+    total = total + s;
+  }
+  return (row[chosen] - m) - orc_log(total);
+}
+void orc_logprob_rows(const float* logits, int rows, int vocab, const int32_t* chosen, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int r = 0; r < rows; ++r) out[r] = orc_logprob_row(logits + (size_t)r * vocab, vocab, chosen[r]);
+}
+void orc_log_vec(const float* in, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_log(in[i]);
+}
+
 /* ---------------------------------------------------------------- rmsnorm */
 /* x: bf16 [E]; scale bf16 [E]; out bf16 [E].
  * sumsq: chunks of 8 consecutive elements -> fma chain from 0; blocks of 64

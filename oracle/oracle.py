@@ -74,6 +74,8 @@ def lib():
     _lib.orc_f32_to_bf16.argtypes = [_f32p, _u16p, ctypes.c_int64]
     _lib.orc_exp_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
     _lib.orc_swiglu.argtypes = [_u16p, _u16p, _u16p, ctypes.c_int64]
+    _lib.orc_log_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
+    _lib.orc_logprob_rows.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, _i32p, _f32p]
     _lib.orc_num_threads.restype = ctypes.c_int
     _lib.orc_set_num_threads.argtypes = [ctypes.c_int]
   return _lib
@@ -93,6 +95,15 @@ def f32_to_bf16(x: np.ndarray) -> np.ndarray:
 
 def bf16_to_f32(h: np.ndarray) -> np.ndarray:
   return (np.ascontiguousarray(h, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32)
+
+
+def logprob_rows(logits: np.ndarray, chosen: np.ndarray) -> np.ndarray:
+  """inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63) in the canonical order of ixt_oracle.c: f32 [rows]."""
+  lg = np.ascontiguousarray(logits, np.float32).reshape(-1, logits.shape[-1])
+  ch = np.ascontiguousarray(chosen, np.int32).reshape(-1)
+  out = np.zeros((lg.shape[0],), np.float32)
+  lib().orc_logprob_rows(_p(lg, _f32p), lg.shape[0], lg.shape[1], _p(ch, _i32p), _p(out, _f32p))
+  return out
 
 
 # ----------------------------------------------------------------------------- RoPE tables

@@ -475,3 +475,45 @@ def test_engine_factory_helpers(tmp_path):
   assert outs[0] == outs[1]
   del a, b
   torch.cuda.synchronize()
+
+
+def test_return_log_prob_outputs():
+  """config.return_log_prob (maxengine.py:502-516, 801-815, 907-926): ResultTokens.log_prob = log_softmax(logits)[token] of the first token
+  (prefill, prefill_concat, prefill_multisampling) and of every generated token, bit-exact against the oracle's restatement of
+  inference_utils.log_prob_of_chosen_token over the same logits."""
+  import torch
+  from oracle import oracle as O
+  cfg = H.make_config(per_device_batch_size=3.0, return_log_prob=True, ixt_staging_groups=2, ixt_max_packed_rows=64, pagedattn_num_pages=40)
+  w = H.synth.synth_weights(cfg, 5)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  toks, tl = H.synth.synth_prompt(cfg.vocab_size, 32, 77)
+  pre, res = eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=0)
+  opre, ores = orc.prefill(toks, tl, slot=0, want_logits=True)
+  want = O.logprob_rows(opre["logits"].reshape(1, -1), ores[:, 0])
+  assert res.log_prob.shape == (1, 1)
+  assert np.array_equal(res.log_prob.cpu().numpy().reshape(-1).view(np.uint32), want.view(np.uint32))
+  _, resm = eng.prefill_multisampling(params=params, padded_tokens=toks, true_length=tl, num_samples=2, slot=1)
+  assert resm.log_prob.shape == (2, 1) and np.array_equal(resm.log_prob.cpu().numpy().reshape(-1).view(np.uint32), np.repeat(want, 2).view(np.uint32))
+  ds = eng.insert(pre, eng.init_decode_state(), 0)
+  ods = orc.insert(opre, orc.init_decode_state(), 0)
+  for step in range(4):
+    ds, r = eng.generate(params, ds)
+    ods, orr = orc.generate(ods, want_logits=True)
+    assert np.array_equal(r.data.cpu().numpy()[0], orr[0])
+    want = O.logprob_rows(ods["logits"][0:1].reshape(1, -1), orr[0:1, 0])
+    assert r.log_prob.shape == (3, 1)
+    assert np.array_equal(r.log_prob.cpu().numpy()[0].view(np.uint32), want.view(np.uint32)), step
+  from test_gpu_engine import _packed_inputs as _pi
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, 32, 900 + s)[0], 9 + 5 * s) for s in range(2)]
+  t2, pos, seg, starts, ln = _pi(prompts)
+  _, pres, results = eng.prefill_concat(params=params, padded_tokens=t2, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts, true_lengths=ln,
+                                        num_prompts=2)
+  lg = pres["logits"].reshape(2, -1).cpu().numpy()
+  want = O.logprob_rows(lg, pres["tokens"].reshape(2).cpu().numpy())
+  got = np.concatenate([r.log_prob.cpu().numpy().reshape(-1) for r in results])
+  assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+  with pytest.raises(NotImplementedError):
+    eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=2, return_prompt_logp=True)
+  del eng
+  torch.cuda.synchronize()

@@ -264,3 +264,22 @@ def test_synth_prompt_contract():
   audio = toks[48:tl]
   assert np.all(((audio >= 6) & (audio <= 104)) | ((audio >= 256001) & (audio <= 264093)))
   assert np.all(toks[tl:] == 0)
+
+
+def test_log_and_logprob_restatement():
+  """orc_log (the device's ixt_log: IEEE-only operations) against libm, and log_prob_of_chosen_token (inference_utils.py:56-63) in the
+  canonical order against a float64 log_softmax."""
+  rng = np.random.default_rng(3)
+  x = np.concatenate([np.exp(rng.uniform(-20, 20, 20000)), [1.0, 2.0, 0.5, 1.41421354, 1.4142137, 264192.0, 1e-30, 3e38]]).astype(np.float32)
+  got = np.zeros_like(x)
+  O.lib().orc_log_vec(O._p(x, O._f32p), O._p(got, O._f32p), x.size)
+  ref = np.log(x.astype(np.float64))
+  assert np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref))) < 2.5e-7
+  V = 5000
+  lg = O.bf16_to_f32(O.f32_to_bf16(rng.normal(0, 4, (7, V)).astype(np.float32))).reshape(7, V)
+  ch = rng.integers(0, V, 7).astype(np.int32)
+  lp = O.logprob_rows(lg, ch)
+  l64 = lg.astype(np.float64)
+  ref = l64[np.arange(7), ch] - (l64.max(1) + np.log(np.exp(l64 - l64.max(1, keepdims=True)).sum(1)))
+  assert np.max(np.abs(lp - ref)) < 2e-5
+  assert np.all(lp <= 0.0)
