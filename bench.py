@@ -274,6 +274,7 @@ def run_rank(args):
     if not args.no_batch_rows:
       _log("long-prompt chunked prefill row")
       out["detail"]["long_prefill"] = long_prefill_row(args, weights, nums)
+      out["detail"]["long_prefill_chunk1024"] = long_prefill_row(args, weights, nums, chunk=1024)
       out["detail"]["batch_rows"] = []
       for b in (1, 8):
         out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
@@ -399,15 +400,15 @@ def batch_row(args, b, weights, prompts_dev, nums):
           "hbm_bound_tokens_per_s": bound}
 
 
-def long_prefill_row(args, weights, nums, total=4096):
+def long_prefill_row(args, weights, nums, total=4096, chunk=None):
   """BASELINE.json configs[3]'s prefill shape on the C2 model: ONE prompt of `total` tokens through the engine's chunked prefill (chunks of
-  --prefill-len rows; each chunk attends to everything before it through the pages: k_attn_tile with a growing key range)."""
+  `chunk` rows, default --prefill-len; each chunk attends to everything before it through the pages: k_attn_tile with a growing key range)."""
   import numpy as np
   import torch
   pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
   maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
   synth = importlib.import_module("maxtext-indextts2_amd.synth")
-  P = args.prefill_len
+  P = chunk or args.prefill_len
   cfg = pyconfig.initialize(["bench", os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")], model_name=args.model, attention="paged", scan_layers=False,
                             per_device_batch_size=1.0, max_prefill_predict_length=P, max_target_length=total + 32, pagedattn_tokens_per_page=32,
                             pagedattn_num_pages=(total + 32) // 32 + 2, ixt_use_hip_graph=False, run_name="bench", use_chunked_prefill=True,
