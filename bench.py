@@ -6,7 +6,7 @@ configs[1], "C2"), data-parallel over N GPUs of one node (one process per GPU, n
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 1024, the engine's maximum) utterances per GPU,
-each a 256-token prompt (4 s reference speech + 128-char text) prefilled -- `--prefill-pack` (default 8)
+each a 256-token prompt (4 s reference speech + 128-char text) prefilled -- `--prefill-pack` (default 16)
 prompts per pass over the weights through the engine's prefill_concat / insert_partial (maxengine.py:719-836, 1206-1318) -- then
 `--decode-steps` (default 1024) greedy generate calls for all slots.  Tokens counted = generated audio tokens
 including the first one from prefill (decode.py:162-178: T-P generate calls yield T-P+1 tokens per utterance).
@@ -45,7 +45,7 @@ def parse(argv=None):
   ap.add_argument("--batch", type=int, default=1024, help="utterances (decode slots) per GPU; 1024 (172 GB of paged K/V at 1280 tokens each) is the engine's maximum")
   ap.add_argument("--decode-steps", type=int, default=1024)
   ap.add_argument("--prefill-len", type=int, default=256)
-  ap.add_argument("--prefill-pack", type=int, default=8, help="prompts per packed prefill (prefill_concat); 1 = one prefill call per utterance")
+  ap.add_argument("--prefill-pack", type=int, default=16, help="prompts per packed prefill (prefill_concat); 1 = one prefill call per utterance")
   ap.add_argument("--model", default="indextts2-1b")
   ap.add_argument("--no-graph", action="store_true")
   ap.add_argument("--no-cpu-baseline", action="store_true")

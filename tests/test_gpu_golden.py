@@ -118,6 +118,55 @@ def test_golden_c2_rows(c2_weights, name, packed):
   torch.cuda.synchronize()
 
 
+def test_c2_packed_4096_rows_equals_two_halves(c2_weights):
+  """The bench's packed prefill shape (16 prompts x 256 tokens = 4096 rows in one pass: every layer GEMM -- also O and MLP down with the residual
+  epilogue -- in the two-blocks-per-CU ring form) against the same prompts in two passes of 2048 rows (the 64-k chunk form for O / MLP down, whose
+  fixtures pin it to the oracle): first tokens, f32 logits and the K/V of two layers must be identical bit for bit."""
+  import torch
+  n, L = 16, 256
+  cfg = H.make_config(model_name="indextts2-1b", per_device_batch_size=float(n), max_prefill_predict_length=L, max_target_length=L + 32,
+                      pagedattn_tokens_per_page=32, pagedattn_num_pages=2 * n * 9 + 1, ixt_staging_groups=n, ixt_max_packed_rows=n * L)
+  eng, params = H.make_engine(cfg, c2_weights[1])
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, L, 8100 + s)[0], L) for s in range(n)]
+
+  def run(groups):
+    firsts, logits, kv = [], [], []
+    ds = eng.init_decode_state()
+    slot0 = 0
+    for grp in groups:
+      t, pos, seg, starts, ln = _packed(grp)
+      cache, pres, _ = eng.prefill_concat(params=params, padded_tokens=t, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts, true_lengths=ln,
+                                          num_prompts=len(grp))
+      firsts.append(pres["tokens"].reshape(-1).cpu().numpy().copy())
+      logits.append(pres["logits"].reshape(len(grp), -1).cpu().numpy().view(np.uint32).copy())
+      slots = np.arange(slot0, slot0 + len(grp))
+      ds = eng.insert_partial(pres, ds, cache, slots, start_indices=starts, num_prompts=len(grp), seq_len=L)
+      slot0 += len(grp)
+    for s in (0, n - 1):
+      for layer in (0, cfg.num_decoder_layers - 1):
+        kv.append(tuple(H.bits(x).copy() for x in eng.gather_kv(layer, s, L)))
+    for s in range(n):
+      eng.release_pages(s)
+    return np.concatenate(firsts), np.concatenate(logits), kv
+  a = run([prompts])
+  b = run([prompts[:8], prompts[8:]])
+  assert np.array_equal(a[0], b[0])
+  assert np.array_equal(a[1], b[1])
+  for (ka, va), (kb, vb) in zip(a[2], b[2]):
+    assert np.array_equal(ka, kb) and np.array_equal(va, vb)
+  del eng
+  torch.cuda.synchronize()
+
+
+def _packed(prompts):
+  lens = np.array([tl for _, tl in prompts], np.int32)
+  toks = np.concatenate([np.asarray(t, np.int32)[:tl] for t, tl in prompts])
+  pos = np.concatenate([np.arange(tl) for tl in lens]).astype(np.int32)
+  seg = np.concatenate([np.full(tl, i + 1) for i, tl in enumerate(lens)]).astype(np.int32)
+  starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+  return toks, pos, seg, starts, lens
+
+
 def test_golden_c2_full_decode(c2_weights):
   """BASELINE.json configs[1] at full size: every one of the 1025 token ids equals the oracle's."""
   g, w = c2_weights
