@@ -52,7 +52,22 @@ typedef struct ixt_config {
   int32_t max_packed_rows;         /* build knob: most rows of one ixt_prefill_rows call (0: max_prefill_predict_length) */
   int32_t staging_groups;          /* build knob: page groups behind the decode slots that a packed prefill (MaxEngine.prefill_concat,
                                       maxengine.py:719-836) fills before insert_partial hands their pages to slots; 0 = none */
+  /* Decoder block variant.  All zero = the llama2 block (llama2.py:54-169).
+   * IXT_BLOCK_GEMMA2 (layers/gemma2.py:69-236, configs/models/gemma2-2b.yml): `num_decoder_layers` counts the reference's merged
+   * [local, global] layers; the context then holds 2 x num_decoder_layers (attention, MLP) sub-layers -- sub-layer 2 i is layer i's
+   * "local" half, 2 i + 1 its "global" half -- and every `layer` argument of this header (ixt_kv_gather, ixt_op_kv_write,
+   * ixt_op_paged_attention) indexes sub-layers.  The fields below are read for gemma2 only and must be zero otherwise. */
+  int32_t decoder_block;           /* base.yml decoder_block: IXT_BLOCK_LLAMA2 | IXT_BLOCK_GEMMA2 */
+  float attn_logits_soft_cap;      /* attentions.py:1257-1259: score = tanh(score / cap) * cap in f32 before the softmax; 0 = none */
+  float final_logits_soft_cap;     /* decoders.py:563-565 (inside the logits_via_embedding branch, as in the reference); 0 = none */
+  int32_t sliding_window_size;     /* attentions.py:625-631, local sub-layers: key j visible iff pos - window < j <= pos; 0 = none */
+  int32_t use_post_attn_norm;      /* gemma2.py:107-116, :195-203: RMSNorm of the attention output before the residual add */
+  int32_t use_post_ffw_norm;       /* gemma2.py:135-143, :227-235: RMSNorm of the MLP output before the residual add */
+  int32_t logits_via_embedding;    /* decoders.py:552-558: logits = y . embedding^T (no logits_dense kernel is loaded) */
+  int32_t normalize_embedding_logits; /* decoders.py:560-562: logits / sqrt(emb_dim), in f32 (the divisor is an f32 array) */
 } ixt_config;
+
+enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1 };
 
 typedef struct ixt_ctx ixt_ctx;
 
@@ -155,6 +170,9 @@ int ixt_op_rmsnorm(ixt_ctx* ctx, const uint16_t* x, const uint16_t* scale, uint1
 int ixt_op_rope(ixt_ctx* ctx, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream);
 /* MlpBlock gate (linears.py:459-464): out = bf16(bf16(silu(a)) * b), n elements. */
 int ixt_op_swiglu(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
+/* The Gemma gate (mlp_activations ["gelu", "linear"], linears.py:449-464 with jax.nn.gelu approximate=True on bf16 values, every primitive
+ * rounded to bf16): out = bf16(bf16(a * cdf(a)) * b), cdf = 0.5 (1 + tanh(sqrt(2/pi) (a + 0.044715 a^3))). */
+int ixt_op_geglu(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
 /* Residual add of the decoder block (llama2.py:127, :157): out = bf16(a + b), n elements. */
 int ixt_op_residual(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
 /* Embed.__call__ (embeddings.py:131-163): out bf16[R][E] = table bf16[V][E] rows ids[R] (ids clamped to the table, as a jnp gather is). */

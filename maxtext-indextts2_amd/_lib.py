@@ -30,7 +30,12 @@ class IxtConfig(ctypes.Structure):
       ("pagedattn_num_pages", ctypes.c_int32), ("pagedattn_tokens_per_page", ctypes.c_int32),
       ("pagedattn_max_pages_per_group", ctypes.c_int32), ("use_hip_graph", ctypes.c_int32),
       ("max_packed_rows", ctypes.c_int32), ("staging_groups", ctypes.c_int32),
+      ("decoder_block", ctypes.c_int32), ("attn_logits_soft_cap", ctypes.c_float), ("final_logits_soft_cap", ctypes.c_float),
+      ("sliding_window_size", ctypes.c_int32), ("use_post_attn_norm", ctypes.c_int32), ("use_post_ffw_norm", ctypes.c_int32),
+      ("logits_via_embedding", ctypes.c_int32), ("normalize_embedding_logits", ctypes.c_int32),
   ]
+
+BLOCK_LLAMA2, BLOCK_GEMMA2 = 0, 1
 
 
 # name -> (restype, argtypes); every symbol include/ixt.h declares
@@ -62,6 +67,7 @@ SIGNATURES = {
     "ixt_op_rmsnorm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_rope": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_swiglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
+    "ixt_op_geglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_residual": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_embed": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_kv_write": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp]),

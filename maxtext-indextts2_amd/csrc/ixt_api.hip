@@ -2,6 +2,7 @@
 // Host code here is plumbing only: argument checks, HBM ownership, launch geometry, hipGraph capture.
 #include "../../include/ixt.h"
 #include "ixt_kernels.h"
+#include "ixt_gemma_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -33,9 +34,10 @@ extern "C" const char* ixt_last_error(void) { return g_err; }
 
 struct LayerW {
   bf16_t *ln1, *wqkv, *wo, *ln2, *wi, *wout;
+  bf16_t *pan = nullptr, *pfn = nullptr;   // Gemma-2: post-attention / post-MLP norm scales
 };
 
-enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER };
+enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER, W_PAN = W_PER_LAYER, W_PFN };
 
 struct TimingPair { hipEvent_t a, b; double bytes; int family; };   // family: 0 canonical dot (incl. unembedding), 1 one-launch decode attention
 
@@ -95,6 +97,11 @@ struct ixt_ctx {
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
+  // Gemma-2 block (ixt_config.decoder_block == 1): L counts (attention, MLP) sub-layers, two per reference layer (even: local sliding)
+  bool gemma = false;
+  float pv_cap = 0.0f;       // soft cap / window of the attention launch being issued (k_attn_pv)
+  int pv_window = 0;
+  float* glogits = nullptr;  // [NLmax][V] logits rows when the caller asks for none (the cap and the sampling need them)
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
   // graphs keyed by the pointer tuple of ixt_generate
@@ -142,6 +149,12 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
   const ixt_config& c = *cfg;
   if (c.head_dim != 64 && c.head_dim != 128) return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 or 128 built)", c.head_dim);
+  if (c.decoder_block != IXT_BLOCK_LLAMA2 && c.decoder_block != IXT_BLOCK_GEMMA2) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2 and gemma2 built)", c.decoder_block);
+  const bool gemma = c.decoder_block == IXT_BLOCK_GEMMA2;
+  if (!gemma && (c.attn_logits_soft_cap != 0.0f || c.final_logits_soft_cap != 0.0f || c.sliding_window_size != 0 || c.use_post_attn_norm || c.use_post_ffw_norm ||
+                 c.logits_via_embedding))
+    return set_err(IXT_ERR_UNSUPPORTED, "soft caps, sliding window, post norms and the tied head are built for decoder_block gemma2 only");
+  if (c.attn_logits_soft_cap < 0.0f || c.final_logits_soft_cap < 0.0f || c.sliding_window_size < 0) return set_err(IXT_ERR_INVALID, "negative soft cap or window");
   if (c.emb_dim % IXT_KALIGN || c.mlp_dim % IXT_KALIGN || (c.num_query_heads * c.head_dim) % IXT_KALIGN)
     return set_err(IXT_ERR_UNSUPPORTED, "emb_dim, mlp_dim and num_query_heads*head_dim must be multiples of %d", IXT_KALIGN);
   if (c.num_kv_heads <= 0 || c.num_query_heads % c.num_kv_heads) return set_err(IXT_ERR_INVALID, "num_query_heads %% num_kv_heads != 0");
@@ -164,7 +177,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   ixt_ctx* x = new ixt_ctx();
   x->cfg = c;
   x->E = c.emb_dim; x->Q = c.num_query_heads; x->KV = c.num_kv_heads; x->D = c.head_dim; x->F = c.mlp_dim;
-  x->V = c.vocab_size; x->L = c.num_decoder_layers; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
+  x->V = c.vocab_size; x->L = c.num_decoder_layers * (gemma ? 2 : 1); x->gemma = gemma; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
   x->QN = x->Q * x->D; x->KN = x->KV * x->D; x->NQKV = x->QN + 2 * x->KN; x->Tmax = c.max_target_length;
   x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
   x->nsb_max = (x->mpg + IXT_SB - 1) / IXT_SB;
@@ -191,7 +204,10 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     A(dmalloc(x, &w.ln2, (size_t)E));
     A(dmalloc(x, &w.wi, (size_t)E * 2 * F));
     A(dmalloc(x, &w.wout, (size_t)F * E));
+    if (gemma && c.use_post_attn_norm) A(dmalloc(x, &w.pan, (size_t)E));
+    if (gemma && c.use_post_ffw_norm) A(dmalloc(x, &w.pfn, (size_t)E));
   }
+  if (gemma) A(dmalloc(x, &x->glogits, (size_t)x->NLmax * V));
   // RoPE tables
   host_rope_tables(c, x->rope_sin_h, x->rope_cos_h);
   A(dmalloc(x, &x->rope_sin, x->rope_sin_h.size()));
@@ -321,7 +337,18 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
     return IXT_OK;
   };
   if (p == "token_embedder/embedding") {
-    TRY(expect((int64_t)V * E)); TRY(copy_param(dev_ptr, dtype, c->embedding, V, E, E, st)); c->loaded[c->L] |= 1; return IXT_OK;
+    TRY(expect((int64_t)V * E)); TRY(copy_param(dev_ptr, dtype, c->embedding, V, E, E, st)); c->loaded[c->L] |= 1;
+    if (c->cfg.logits_via_embedding) {   // decoders.py:552-558: the transposed table is the logits kernel
+      bf16_t* tmp = nullptr;
+      HIPCHK(hipMalloc((void**)&tmp, (size_t)V * E * sizeof(bf16_t)));
+      hipLaunchKernelGGL(k_transpose_ve, dim3((V + 31) / 32, (E + 31) / 32), dim3(32, 8), 0, st, c->embedding, tmp, V, E);
+      int rc = tile_param(tmp, IXT_BF16, c->logits_w, E, V, 0, st);
+      (void)hipStreamSynchronize(st);
+      (void)hipFree(tmp);
+      TRY(rc);
+      c->loaded[c->L] |= 4;
+    }
+    return IXT_OK;
   }
   if (p == "decoder/decoder_norm/scale") {
     TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, c->final_norm, 1, E, E, st)); c->loaded[c->L] |= 2; return IXT_OK;
@@ -332,7 +359,30 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
   int li = -1, consumed = 0;
   if (sscanf(p.c_str(), "decoder/layers_%d/%n", &li, &consumed) < 1 || li < 0 || li >= c->L || consumed == 0)
     return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
-  const std::string rest = p.substr(consumed);
+  std::string rest = p.substr(consumed);
+  if (c->gemma) {
+    // layers/gemma2.py:69-236: reference layer li holds a "local" and a "global" (attention, MLP) pair = sub-layers 2 li and 2 li + 1.
+    // The names are mapped onto the llama2 spellings below; the post norms are Gemma's own.
+    if (li >= c->L / 2) return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
+    int sub = -1;
+    const char* tags[2] = {"_local", "_global"};
+    for (int t = 0; t < 2 && sub < 0; ++t) {
+      const std::string tag(tags[t]);
+      const size_t slash = rest.find('/');
+      const std::string head = rest.substr(0, slash);
+      if (head.size() > tag.size() && head.compare(head.size() - tag.size(), tag.size(), tag) == 0) {
+        sub = t;
+        rest = head.substr(0, head.size() - tag.size()) + (slash == std::string::npos ? "" : rest.substr(slash));
+      }
+    }
+    if (sub < 0) return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
+    li = 2 * li + sub;
+    if (rest == "pre_self_attention_norm/scale") rest = "pre_self_attention_layer_norm/scale";
+    else if (rest == "pre_ffw_norm/scale") rest = "mlp/mlp_layer_norm/scale";
+    LayerW& gw = c->layers[li];
+    if (rest == "post_self_attention_norm/scale" && gw.pan) { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, gw.pan, 1, E, E, st)); c->loaded[li] |= 1u << W_PAN; return IXT_OK; }
+    if (rest == "post_ffw_norm/scale" && gw.pfn) { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, gw.pfn, 1, E, E, st)); c->loaded[li] |= 1u << W_PFN; return IXT_OK; }
+  }
   LayerW& w = c->layers[li];
   uint32_t& m = c->loaded[li];
   if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
@@ -350,8 +400,12 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
 
 extern "C" int ixt_weights_complete(ixt_ctx* c) {
   if (!c) return 0;
-  for (int i = 0; i < c->L; ++i)
-    if (c->loaded[i] != (1u << W_PER_LAYER) - 1) return 0;
+  for (int i = 0; i < c->L; ++i) {
+    uint32_t want = (1u << W_PER_LAYER) - 1;
+    if (c->layers[i].pan) want |= 1u << W_PAN;
+    if (c->layers[i].pfn) want |= 1u << W_PFN;
+    if (c->loaded[i] != want) return 0;
+  }
   return c->loaded[c->L] == 7 ? 1 : 0;
 }
 
@@ -794,7 +848,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
   PvArgs pa;
   pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
-  pa.pvpart = c->pvpart; pa.g = g;
+  pa.pvpart = c->pvpart; pa.g = g; pa.cap = c->pv_cap; pa.window = c->pv_window;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
   hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, out, g, 0);
@@ -843,7 +897,7 @@ static void launch_front_pv(ixt_ctx* c, int layer, int R, int len_hint, const Do
   PvArgs pa;
   pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
-  pa.pvpart = c->pvpart; pa.g = g;
+  pa.pvpart = c->pvpart; pa.g = g; pa.cap = c->pv_cap; pa.window = c->pv_window;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
 }
@@ -866,7 +920,7 @@ static void launch_scores_pv(ixt_ctx* c, int layer, int R, int len_hint, hipStre
   PvArgs pa;
   pa.scores = c->scores; pa.vpages = c->vpages_l[layer];
   pa.row_slot = c->row_slot; pa.row_pos = c->row_pos; pa.row_active = c->row_active; pa.page_map = c->ps.page_map;
-  pa.pvpart = c->pvpart; pa.g = g;
+  pa.pvpart = c->pvpart; pa.g = g; pa.cap = c->pv_cap; pa.window = c->pv_window;
   const size_t lds = sizeof(float) * ((size_t)g.mpg * g.P + g.mpg + 8);
   hipLaunchKernelGGL((k_attn_pv<HD, GQ>), dim3(R, g.nkv, nchunk), dim3(256), lds, st, pa);
 }
@@ -955,6 +1009,72 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
 
+// The Gemma-2 block over R rows (layers/gemma2.py:69-236): per (attention, MLP) sub-layer
+//   QKV dot -> k_qkv_finalize (RoPE, q -> qbuf, K/V -> pages) -> scores / softmax + PV (soft cap; sliding window on the even, "local"
+//   sub-layers) / combine -> O dot -> k_gnorm (post norm, residual, pre-MLP norm) -> wi dot -> GELU gate -> down dot -> k_gnorm (post norm,
+//   residual, the next pre-attention norm or the final norm).  Prefill and decode rows take the same launches: every row's K/V is in its
+//   page before any score is computed, and a row never sees a key beyond its own position.
+// Logits: unembedding (dense kernel, or the transposed embedding when logits_via_embedding), then k_logits_post (/ sqrt(emb), soft cap,
+// greedy sampling over the allowed columns -- the cap is not strictly monotone after rounding, so the maximum is taken after it).
+static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
+                               float* logits_out, hipStream_t st) {
+  const int E = c->E, F = c->F;
+  const ixt_config& cf = c->cfg;
+  DotResult dr;
+  bf16_t* hcur = c->h_a;
+  bf16_t* hnext = c->h_b;
+  const bool all_rows = nl == R && lrow0 == 0 && lrows == nullptr;
+  const size_t glds = sizeof(float) * ((size_t)E + 128);
+  TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    TRY(launch_dot(c, c->xn, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
+    QkvArgs qa;
+    qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
+    qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
+    qa.rope_sin = c->rope_sin; qa.rope_cos = c->rope_cos; qa.qbuf = c->qbuf;
+    qa.kpages = c->kpages_l[l]; qa.vpages = c->vpages_l[l];
+    qa.g = c->geom;
+    hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
+    LAUNCHCHK();
+    c->pv_cap = cf.attn_logits_soft_cap;
+    c->pv_window = (l % 2 == 0) ? cf.sliding_window_size : 0;
+    int rc = launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st);
+    c->pv_cap = 0.0f; c->pv_window = 0;
+    TRY(rc);
+    hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
+    LAUNCHCHK();
+    TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
+    GNormArgs ga;
+    ga.part = c->part; ga.slices = dr.slices; ga.slice_stride = dr.slice_stride; ga.h_in = hcur; ga.h_out = hnext;
+    ga.post = w.pan; ga.next = w.ln2; ga.xn_out = c->xn; ga.E = E; ga.eps = cf.normalization_layer_epsilon;
+    hipLaunchKernelGGL(k_gnorm, dim3(R), dim3(256), glds, st, ga);
+    LAUNCHCHK();
+    TRY(launch_dot(c, c->xn, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
+    hipLaunchKernelGGL(k_geglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
+    LAUNCHCHK();
+    TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr));
+    ga.part = c->part; ga.slices = dr.slices; ga.slice_stride = dr.slice_stride; ga.h_in = hnext; ga.h_out = hcur;
+    ga.post = w.pfn; ga.next = l + 1 < c->L ? c->layers[l + 1].ln1 : (all_rows ? c->final_norm : nullptr);
+    hipLaunchKernelGGL(k_gnorm, dim3(R), dim3(256), glds, st, ga);
+    LAUNCHCHK();
+  }
+  if (nl > 0) {
+    if (nl > c->NLmax) return set_err(IXT_ERR_INVALID, "too many logits rows (%d > %d)", nl, c->NLmax);
+    if (!all_rows) TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, lrows ? hcur : hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st, 1, lrows));
+    float* lg = logits_out ? logits_out : c->glogits;
+    TRY(launch_unembed(c, c->xn, nl, lg, argmax_out, st));
+    // decoders.py:552-565: the division and the cap belong to the tied head
+    const int normalize = cf.logits_via_embedding && cf.normalize_embedding_logits;
+    const float cap = cf.logits_via_embedding ? cf.final_logits_soft_cap : 0.0f;
+    if (normalize || cap > 0.0f) {
+      hipLaunchKernelGGL(k_logits_post, dim3(nl), dim3(256), 0, st, lg, c->V, normalize, sqrtf((float)E), cap, c->sample_cols, argmax_out);
+      LAUNCHCHK();
+    }
+  }
+  return IXT_OK;
+}
+
 // The model over R rows described by row_slot/row_pos/row_active (device) and `tokens`.
 // Logits: nl rows -- rows [lrow0, lrow0 + nl) when lrows == nullptr, else the rows listed in lrows (device, nl entries).
 // decode: one new token per row (rows never read each other's new K).
@@ -968,6 +1088,7 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
+  if (c->gemma) return forward_rows_gemma2(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, st);
   const int E = c->E, F = c->F;
   DotResult dr;
   bf16_t* hcur = c->h_a;
@@ -1227,6 +1348,13 @@ extern "C" int ixt_op_rope(ixt_ctx* c, uint16_t* x, const int32_t* pos, int R, i
 extern "C" int ixt_op_swiglu(ixt_ctx* c, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
   if (!c || !a || !b || !out || n <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipLaunchKernelGGL(k_swiglu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_geglu(ixt_ctx* c, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream) {
+  if (!c || !a || !b || !out || n < 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_geglu, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, n);
   LAUNCHCHK();
   return IXT_OK;
 }

@@ -73,6 +73,38 @@ __device__ __forceinline__ bf16_t ixt_swiglu(float a, float b) {
   return f2bf(u * b);
 }
 
+// tanh from IEEE-only operations.  |x| < 1/16: odd series x (1 - x^2/3 + 2 x^4/15 - 17 x^6/315) by Horner fma (next term < 2e-13 relative);
+// |x| >= 10: 1 (1 - tanh < 2^-25); else (1 - e) / (1 + e), e = ixt_exp(-2 |x|).  Sign copied from x.
+__device__ __forceinline__ float ixt_tanh(float x) {
+  const float a = fabsf(x);
+  float t;
+  if (a < 0.0625f) {
+    const float w = a * a;
+    float p = -5.39682539682539682540e-2f;
+    p = __builtin_fmaf(p, w, 1.33333333333333333333e-1f);
+    p = __builtin_fmaf(p, w, -3.33333333333333333333e-1f);
+    p = __builtin_fmaf(p, w, 1.0f);
+    t = a * p;
+  } else if (a >= 10.0f) {
+    t = 1.0f;
+  } else {
+    const float e = ixt_exp(-2.0f * a);
+    t = (1.0f - e) / (1.0f + e);
+  }
+  return copysignf(t, x);
+}
+
+// Gemma MlpBlock gate (mlp_activations ["gelu", "linear"], linears.py:449-464; jax.nn.gelu approximate=True on bf16 values, every
+// primitive rounded to bf16): cdf = 0.5 (1 + tanh(c (a + 0.044715 a^3))), bf16(bf16(a * cdf) * b)
+__device__ __forceinline__ bf16_t ixt_geglu(float a, float b) {
+  const float x3 = rbf(rbf(a * a) * a);
+  const float u = rbf(a + rbf(0.044677734375f * x3));       // bf16(0.044715)
+  const float th = rbf(ixt_tanh(rbf(0.796875f * u)));       // bf16(sqrt(2 / pi))
+  const float cdf = rbf(0.5f * rbf(1.0f + th));
+  const float g = rbf(a * cdf);
+  return f2bf(g * b);
+}
+
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // agent-scope (L1-bypassing) accesses for state one wave re-reads after writing it

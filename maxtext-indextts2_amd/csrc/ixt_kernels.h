@@ -966,6 +966,8 @@ struct PvArgs {
   const int32_t* row_slot; const int32_t* row_pos; const int32_t* row_active; const int32_t* page_map;
   float* pvpart;      // [R][nq][nsb_max][hd]
   AttnGeom g;
+  float cap;          // > 0: score = ixt_tanh(score / cap) * cap before the max (attn_logits_soft_cap, attentions.py:1257-1259)
+  int window;         // > 0: keys j <= pos - window are invisible (LOCAL_SLIDING, attentions.py:625-631): e_j = p_j = +0, every sum unchanged
 };
 
 template <int HD, int GQ>
@@ -986,6 +988,7 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
   constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
   const int j0 = chunk * 4 * IXT_SB * g.P;  // first key of this block's range
   const int j1 = min(kv_len, j0 + 4 * IXT_SB * g.P);
+  const int jvis = (a.window > 0 && kv_len > a.window) ? kv_len - a.window : 0;   // first visible key
 
   for (int q = 0; q < GQ; ++q) {
     const int h = kvh * GQ + q;
@@ -994,16 +997,17 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
     // scores -> LDS (coalesced), max (order independent)
     float m = -INFINITY;
     for (int j = tid; j < kv_len; j += 256) {
-      const float sv = srow[j];
+      float sv = srow[j];
+      if (a.cap > 0.0f) sv = ixt_tanh(sv / a.cap) * a.cap;
       ebuf[j] = sv;
-      m = fmaxf(m, sv);
+      if (j >= jvis) m = fmaxf(m, sv);
     }
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
     if (lane == 0) wred[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(wred[0], wred[1]), fmaxf(wred[2], wred[3]));
-    for (int j = tid; j < kv_len; j += 256) ebuf[j] = ixt_exp(ebuf[j] - m);
+    for (int j = tid; j < kv_len; j += 256) ebuf[j] = j >= jvis ? ixt_exp(ebuf[j] - m) : 0.0f;
     __syncthreads();
     // page sums in key order: thread p owns logical page p
     for (int p = tid; p < pages; p += 256) {

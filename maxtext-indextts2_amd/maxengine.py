@@ -85,6 +85,19 @@ class MaxEngine(engine_api.Engine):
     c.use_hip_graph = 1 if config.ixt_use_hip_graph else 0
     c.max_packed_rows = int(config.ixt_max_packed_rows)
     c.staging_groups = int(config.ixt_staging_groups)
+    if config.decoder_block == "gemma2":          # layers/gemma2.py:69-236
+      if tuple(config.mlp_activations) != ("gelu", "linear"):
+        raise ValueError("decoder_block gemma2 is built with mlp_activations ['gelu', 'linear']")
+      c.decoder_block = _lib.BLOCK_GEMMA2
+      c.attn_logits_soft_cap = float(config.attn_logits_soft_cap or 0.0)
+      c.final_logits_soft_cap = float(config.final_logits_soft_cap or 0.0)
+      c.sliding_window_size = int(config.sliding_window_size or 0)
+      c.use_post_attn_norm = 1 if config.use_post_attn_norm else 0
+      c.use_post_ffw_norm = 1 if config.use_post_ffw_norm else 0
+      c.logits_via_embedding = 1 if config.logits_via_embedding else 0
+      c.normalize_embedding_logits = 1 if config.normalize_embedding_logits else 0
+    elif tuple(config.mlp_activations) != ("silu", "linear"):
+      raise ValueError("decoder_block llama2 is built with mlp_activations ['silu', 'linear']")
     self._staging = int(config.ixt_staging_groups)
     self._packed_rows = max(int(config.ixt_max_packed_rows), int(config.max_prefill_predict_length))
     self._ccfg = c

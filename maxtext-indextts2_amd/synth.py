@@ -57,8 +57,62 @@ def layer_paths(i: int):
   }
 
 
+def gemma2_layer_paths(i: int, sub: str):
+  """layers/gemma2.py:69-236 parameter names of reference layer i; sub = "local" | "global"."""
+  p = f"params/decoder/layers_{i}/"
+  return {
+      "ln1": p + f"pre_self_attention_norm_{sub}/scale",
+      "q": p + f"self_attention_{sub}/query/kernel",
+      "k": p + f"self_attention_{sub}/key/kernel",
+      "v": p + f"self_attention_{sub}/value/kernel",
+      "o": p + f"self_attention_{sub}/out/kernel",
+      "pan": p + f"post_self_attention_norm_{sub}/scale",
+      # the local MLP carries its own pre-norm (mlp_block(use_pre_norm=True), gemma2.py:121-133), the global one is a separate module
+      "ln2": p + ("mlp_local/mlp_layer_norm/scale" if sub == "local" else "pre_ffw_norm_global/scale"),
+      "wi0": p + f"mlp_{sub}/wi_0/kernel",
+      "wi1": p + f"mlp_{sub}/wi_1/kernel",
+      "wo": p + f"mlp_{sub}/wo/kernel",
+      "pfn": p + f"post_ffw_norm_{sub}/scale",
+  }
+
+
+def synth_weights_gemma2(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+  """Random Gemma-2 tree (same distributions as synth_weights); norm scales are drawn around 1 so that every norm is exercised."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
+                          cfg.num_decoder_layers)
+
+  def scale():
+    return f32_to_bf16_bits(1.0 + 0.25 * rng.standard_normal(E, dtype=np.float32))
+
+  w: Dict[str, np.ndarray] = {}
+  w["params/token_embedder/embedding"] = f32_to_bf16_bits(rng.standard_normal(V * E, dtype=np.float32)).reshape(V, E)
+  for i in range(L):
+    for sub in ("local", "global"):
+      p = gemma2_layer_paths(i, sub)
+      w[p["ln1"]] = scale()
+      w[p["q"]] = _dense(rng, (E, Q, D), E, math.sqrt(D))
+      w[p["k"]] = _dense(rng, (E, KV, D), E)
+      w[p["v"]] = _dense(rng, (E, KV, D), E)
+      w[p["o"]] = _dense(rng, (Q, D, E), Q * D)
+      w[p["ln2"]] = scale()
+      w[p["wi0"]] = _dense(rng, (E, F), E)
+      w[p["wi1"]] = _dense(rng, (E, F), E)
+      w[p["wo"]] = _dense(rng, (F, E), F)
+      if getattr(cfg, "use_post_attn_norm", False):
+        w[p["pan"]] = scale()
+      if getattr(cfg, "use_post_ffw_norm", False):
+        w[p["pfn"]] = scale()
+  w["params/decoder/decoder_norm/scale"] = scale()
+  if not getattr(cfg, "logits_via_embedding", False):
+    w["params/decoder/logits_dense/kernel"] = _dense(rng, (E, V), E)
+  return w
+
+
 def synth_weights(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
   """cfg needs vocab_size, emb_dim, num_query_heads, num_kv_heads, head_dim, mlp_dim, num_decoder_layers."""
+  if getattr(cfg, "decoder_block", "llama2") == "gemma2":
+    return synth_weights_gemma2(cfg, seed)
   rng = np.random.Generator(np.random.PCG64(seed))
   E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
                           cfg.num_decoder_layers)

@@ -61,6 +61,15 @@ typedef struct orc_model {
   /* KV pages (oracle-private layout): [L][num_pages][page][nkv][hd] */
   uint16_t* kpages;
   uint16_t* vpages;
+  /* SURVEY.md section 8(f) item 3, Gemma-2 block (layers/gemma2.py:69-236): nlayers then counts (attention, MLP) sub-layers, two per
+   * reference layer: even = local sliding window, odd = global.  All zero / NULL: the llama2 block. */
+  int32_t block;                      /* 0 llama2, 1 gemma2 */
+  float attn_cap;                     /* attn_logits_soft_cap (attentions.py:1257-1259), 0: none */
+  float final_cap;                    /* final_logits_soft_cap (decoders.py:563-565), 0: none */
+  int32_t window;                     /* sliding_window_size of the local sub-layers (attentions.py:625-631), 0: none */
+  int32_t norm_logits;                /* normalize_embedding_logits (decoders.py:560-562): logits / sqrt(emb) in f32 */
+  const uint16_t* const* pan;         /* [L] -> [emb] post_self_attention_norm, NULL: none */
+  const uint16_t* const* pfn;         /* [L] -> [emb] post_ffw_norm, NULL: none */
 } orc_model;
 
 /* ---------------------------------------------------------------- scalars */
@@ -127,6 +136,27 @@ float orc_log(float x) {
   float lf = (z + z) * p;
   float fe = (float)e;
   return fmaf(fe, 0.693145751953125f, fmaf(fe, 1.42860682030941723212e-6f, lf));
+}
+
+/* tanh in IEEE-only operations, identical op sequence to the device implementation (ixt_tanh): |x| < 1/16 the odd series by Horner fma,
+ * |x| >= 10 -> 1, else (1 - e) / (1 + e) with e = orc_exp(-2 |x|). */
+float orc_tanh(float x) {
+  float a = fabsf(x);
+  float t;
+  if (a < 0.0625f) {
+    float w = a * a;
+    float p = -5.39682539682539682540e-2f;                /* -17/315 */
+    p = fmaf(p, w, 1.33333333333333333333e-1f);           /* 2/15 */
+    p = fmaf(p, w, -3.33333333333333333333e-1f);          /* -1/3 */
+    p = fmaf(p, w, 1.0f);
+    t = a * p;
+  } else if (a >= 10.0f) {
+    t = 1.0f;
+  } else {
+    float e = orc_exp(-2.0f * a);
+    t = (1.0f - e) / (1.0f + e);
+  }
+  return copysignf(t, x);
 }
 
 /* inference_utils.log_prob_of_chosen_token (inference_utils.py:56-63) on one row of f32 logits: jax.nn.log_softmax = shifted - log(sum(exp(
@@ -439,8 +469,12 @@ static void dot_rows_bf16(const uint16_t* x, int ldx, int R, const uint16_t* W, 
  *   p_j     : bf16(e_j / l)
  *   out_d   : page chain a_p = 0; a_p = fma(p_j, v_jd, a_p); super-block of 4 pages
  *             s = 0; s += a_p; total t = 0; t += s; bf16(t)                        */
-void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int32_t* page_row, int kv_len, uint16_t* out, float* sc /* [kv_len] scratch */) {
+/* cap > 0: score_j = orc_tanh(score_j / cap) * cap before the max (attentions.py:1257-1259).  window > 0: keys j <= pos - window
+ * (pos = kv_len - 1) are invisible (attentions.py:625-631): their e_j and p_j are +0, which leaves every page sum and chain unchanged. */
+void orc_attend_row_ex(const orc_model* m, int layer, const uint16_t* q, const int32_t* page_row, int kv_len, uint16_t* out, float* sc /* [kv_len] scratch */,
+                       float cap, int window) {
   int hd = m->hd, nkv = m->nkv, nq = m->nq, P = m->page;
+  int start = (window > 0 && kv_len > window) ? kv_len - window : 0;
   int grp = nq / nkv;
   size_t page_elems = (size_t)P * nkv * hd;
   const uint16_t* kp = m->kpages + (size_t)layer * m->num_pages * page_elems;
@@ -458,15 +492,16 @@ void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int3
       const uint16_t* kj = kp + (size_t)page_row[j / P] * page_elems + ((size_t)(j % P) * nkv + kvh) * hd;
       float a = 0.0f;
       for (int d = 0; d < hd; ++d) a = fmaf(bf2f(qh[d]), bf2f(kj[d]), a);
+      if (cap > 0.0f) a = orc_tanh(a / cap) * cap;
       sc[j] = a;
-      if (a > mx) mx = a;
+      if (j >= start && a > mx) mx = a;
     }
     float l = 0.0f;
     for (int p = 0; p < npages; ++p) {
       float s = 0.0f;
       int j1 = (p + 1) * P < kv_len ? (p + 1) * P : kv_len;
       for (int j = p * P; j < j1; ++j) {
-        sc[j] = orc_exp(sc[j] - mx);
+        sc[j] = j >= start ? orc_exp(sc[j] - mx) : 0.0f;
         s = s + sc[j];
       }
       l = l + s;
@@ -495,6 +530,10 @@ void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int3
   }
 }
 
+void orc_attend_row(const orc_model* m, int layer, const uint16_t* q, const int32_t* page_row, int kv_len, uint16_t* out, float* sc) {
+  orc_attend_row_ex(m, layer, q, page_row, kv_len, out, sc, 0.0f, 0);
+}
+
 /* ---------------------------------------------------------------- sampling columns */
 /* greedy sampling restricted to a union of up to 4 half-open column ranges (the audio rows of
  * the expanded vocabulary); n == 0: every column. */
@@ -509,6 +548,34 @@ static inline int orc_col_allowed(int n) {
   for (int i = 0; i < orc_nranges; ++i)
     if (n >= orc_lo[i] && n < orc_hi[i]) return 1;
   return 0;
+}
+
+/* Gemma gate (mlp_activations ["gelu", "linear"], linears.py:449-464; jax.nn.gelu approximate=True on bf16 values, every primitive
+ * rounded to bf16): cdf = 0.5 (1 + tanh(c (a + 0.044715 a^3))), bf16(bf16(a * cdf) * b); the two constants are their bf16 values. */
+uint16_t orc_geglu_one(float a, float b) {
+  float x3 = rbf(rbf(a * a) * a);
+  float u = rbf(a + rbf(0.044677734375f * x3));
+  float th = rbf(orc_tanh(rbf(0.796875f * u)));
+  float cdf = rbf(0.5f * rbf(1.0f + th));
+  float g = rbf(a * cdf);
+  return f2bf(g * b);
+}
+void orc_geglu(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_geglu_one(bf2f(a[i]), bf2f(b[i]));
+}
+void orc_tanh_vec(const float* in, float* out, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) out[i] = orc_tanh(in[i]);
+}
+/* decoders.py:560-565 on one bf16-valued logit.  normalize: the division by jnp.sqrt(emb) (an f32 array) promotes the logits to f32, and
+ * the cap chain stays in f32; otherwise the logits stay bf16 and every primitive of the cap rounds to bf16. */
+float orc_logit_post(float v, int normalize, int emb, float cap) {
+  if (normalize) {
+    v = v / sqrtf((float)emb);
+    if (cap > 0.0f) v = orc_tanh(v / cap) * cap;
+    return v;
+  }
+  if (cap > 0.0f) v = rbf(rbf(orc_tanh(rbf(v / cap))) * cap);
+  return v;
 }
 
 /* ---------------------------------------------------------------- forward */
@@ -544,6 +611,7 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
   int max_len = 0;
   for (int r = 0; r < R; ++r)
     if (pos[r] + 1 > max_len) max_len = pos[r] + 1;
+  const int gemma = m->block == 1;
 
   for (int r = 0; r < R; ++r) memcpy(h + (size_t)r * E, m->embedding + (size_t)tokens[r] * E, sizeof(uint16_t) * E);
 
@@ -572,23 +640,31 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
 #pragma omp for schedule(dynamic, 1)
       for (int r = 0; r < R; ++r) {
         int kv_len = active[r] ? pos[r] + 1 : 0;
-        orc_attend_row(m, L, q + (size_t)r * QN, page_map + (size_t)slot[r] * m->max_pages_per_group, kv_len,
-                       ao + (size_t)r * QN, sc);
+        orc_attend_row_ex(m, L, q + (size_t)r * QN, page_map + (size_t)slot[r] * m->max_pages_per_group, kv_len,
+                          ao + (size_t)r * QN, sc, gemma ? m->attn_cap : 0.0f, (gemma && L % 2 == 0) ? m->window : 0);
       }
       free(sc);
     }
     dot_rows_bf16(ao, QN, R, m->wo[L], QN, E, t0, E, scratch);
+    if (gemma && m->pan)   /* gemma2.py:107-116: the attention output is normalised before the residual add */
+      for (int r = 0; r < R; ++r) orc_rmsnorm(t0 + (size_t)r * E, m->pan[L], t0 + (size_t)r * E, E, m->eps);
     for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
     for (int r = 0; r < R; ++r) orc_rmsnorm(h + (size_t)r * E, m->ln2[L], xn + (size_t)r * E, E, m->eps);
     dot_rows_bf16(xn, E, R, m->wi0[L], E, F, t0, F, scratch);
     dot_rows_bf16(xn, E, R, m->wi1[L], E, F, t1, F, scratch);
     for (size_t i = 0; i < (size_t)R * F; ++i) {
       float a = bf2f(t0[i]);
+      if (gemma) {
+        hact[i] = orc_geglu_one(a, bf2f(t1[i]));
+        continue;
+      }
       float sg = rbf(1.0f / (1.0f + orc_exp(-a)));
       float u = rbf(a * sg);
       hact[i] = f2bf(u * bf2f(t1[i]));
     }
     dot_rows_bf16(hact, F, R, m->wout[L], F, E, t0, E, scratch);
+    if (gemma && m->pfn)   /* gemma2.py:135-143 */
+      for (int r = 0; r < R; ++r) orc_rmsnorm(t0 + (size_t)r * E, m->pfn[L], t0 + (size_t)r * E, E, m->eps);
     for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
   }
   if (hidden_out) memcpy(hidden_out, h, sizeof(uint16_t) * (size_t)R * E);
@@ -607,6 +683,7 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
       float bv = -INFINITY;
       for (int n = 0; n < m->vocab; ++n) {
         float vv = rbf(row[n]);
+        if (gemma) vv = orc_logit_post(vv, m->norm_logits, m->emb, m->final_cap);
         row[n] = vv;
         if (!orc_col_allowed(n)) continue;
         if (best < 0 || vv > bv) { bv = vv; best = n; }

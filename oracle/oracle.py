@@ -53,6 +53,8 @@ class _CModel(ctypes.Structure):
       ("ln2", _u16pp), ("wi0", _u16pp), ("wi1", _u16pp), ("wout", _u16pp),
       ("rope_sin", _u16p), ("rope_cos", _u16p),
       ("kpages", _u16p), ("vpages", _u16p),
+      ("block", ctypes.c_int32), ("attn_cap", ctypes.c_float), ("final_cap", ctypes.c_float), ("window", ctypes.c_int32),
+      ("norm_logits", ctypes.c_int32), ("pan", _u16pp), ("pfn", _u16pp),
   ]
 
 
@@ -74,6 +76,9 @@ def lib():
     _lib.orc_f32_to_bf16.argtypes = [_f32p, _u16p, ctypes.c_int64]
     _lib.orc_exp_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
     _lib.orc_swiglu.argtypes = [_u16p, _u16p, _u16p, ctypes.c_int64]
+    _lib.orc_geglu.argtypes = [_u16p, _u16p, _u16p, ctypes.c_int64]
+    _lib.orc_tanh_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
+    _lib.orc_attend_row_ex.argtypes = [ctypes.POINTER(_CModel), ctypes.c_int, _u16p, _i32p, ctypes.c_int, _u16p, _f32p, ctypes.c_float, ctypes.c_int]
     _lib.orc_log_vec.argtypes = [_f32p, _f32p, ctypes.c_int64]
     _lib.orc_logprob_rows.argtypes = [_f32p, ctypes.c_int, ctypes.c_int, _i32p, _f32p]
     _lib.orc_num_threads.restype = ctypes.c_int
@@ -336,6 +341,20 @@ class OracleConfig:
   pagedattn_tokens_per_page: int = 32
   pagedattn_max_pages_per_group: int = -1
   max_slots: int = 1
+  # Gemma-2 block (configs/models/gemma2-2b.yml): num_decoder_layers counts the reference's merged
+  # [local, global] layers; the model then has 2 x num_decoder_layers (attention, MLP) sub-layers and as many K/V page pools
+  decoder_block: str = "llama2"
+  attn_logits_soft_cap: float = 0.0
+  final_logits_soft_cap: float = 0.0
+  sliding_window_size: int = 0
+  use_post_attn_norm: bool = False
+  use_post_ffw_norm: bool = False
+  logits_via_embedding: bool = False
+  normalize_embedding_logits: bool = True
+
+  @property
+  def sublayers(self) -> int:
+    return self.num_decoder_layers * (2 if self.decoder_block == "gemma2" else 1)
 
   def __post_init__(self):
     if self.pagedattn_max_pages_per_group <= 0:
@@ -350,7 +369,8 @@ class OracleModel:
   def __init__(self, cfg: OracleConfig, weights: Dict[str, np.ndarray]):
     self.cfg = cfg
     self.lib = lib()
-    L = cfg.num_decoder_layers
+    L = cfg.sublayers
+    gemma = cfg.decoder_block == "gemma2"
     self._keep: List[np.ndarray] = []
 
     def w(path, shape):
@@ -375,16 +395,48 @@ class OracleModel:
     m.eps = cfg.normalization_layer_epsilon
     m.embedding = _p(w("params/token_embedder/embedding", (V, E)), _u16p)
     m.final_norm = _p(w("params/decoder/decoder_norm/scale", (E,)), _u16p)
-    m.logits_w = _p(w("params/decoder/logits_dense/kernel", (E, V)), _u16p)
-    m.ln1 = arr([(lp % i + "pre_self_attention_layer_norm/scale", (E,)) for i in range(L)])
-    m.wq = arr([(lp % i + "self_attention/query/kernel", (E, Q, D)) for i in range(L)])
-    m.wk = arr([(lp % i + "self_attention/key/kernel", (E, KV, D)) for i in range(L)])
-    m.wv = arr([(lp % i + "self_attention/value/kernel", (E, KV, D)) for i in range(L)])
-    m.wo = arr([(lp % i + "self_attention/out/kernel", (Q, D, E)) for i in range(L)])
-    m.ln2 = arr([(lp % i + "mlp/mlp_layer_norm/scale", (E,)) for i in range(L)])
-    m.wi0 = arr([(lp % i + "mlp/wi_0/kernel", (E, F)) for i in range(L)])
-    m.wi1 = arr([(lp % i + "mlp/wi_1/kernel", (E, F)) for i in range(L)])
-    m.wout = arr([(lp % i + "mlp/wo/kernel", (F, E)) for i in range(L)])
+    if gemma and cfg.logits_via_embedding:   # decoders.py:552-558: the transposed embedding table is the logits kernel
+      tied = np.ascontiguousarray(np.asarray(weights["params/token_embedder/embedding"]).reshape(V, E).T)
+      self._keep.append(tied)
+      m.logits_w = _p(tied, _u16p)
+    else:
+      m.logits_w = _p(w("params/decoder/logits_dense/kernel", (E, V)), _u16p)
+    if gemma:
+      # layers/gemma2.py:69-236 parameter names; sub-layer 2 i = "local", 2 i + 1 = "global" of reference layer i
+      def names(fmt_local, fmt_global=None):
+        out = []
+        for i in range(cfg.num_decoder_layers):
+          out.append(lp % i + fmt_local.format("local"))
+          out.append(lp % i + (fmt_global or fmt_local).format("global"))
+        return out
+      m.ln1 = arr([(n, (E,)) for n in names("pre_self_attention_norm_{}/scale")])
+      m.wq = arr([(n, (E, Q, D)) for n in names("self_attention_{}/query/kernel")])
+      m.wk = arr([(n, (E, KV, D)) for n in names("self_attention_{}/key/kernel")])
+      m.wv = arr([(n, (E, KV, D)) for n in names("self_attention_{}/value/kernel")])
+      m.wo = arr([(n, (Q, D, E)) for n in names("self_attention_{}/out/kernel")])
+      m.ln2 = arr([(n, (E,)) for n in names("mlp_{}/mlp_layer_norm/scale", "pre_ffw_norm_{}/scale")])
+      m.wi0 = arr([(n, (E, F)) for n in names("mlp_{}/wi_0/kernel")])
+      m.wi1 = arr([(n, (E, F)) for n in names("mlp_{}/wi_1/kernel")])
+      m.wout = arr([(n, (F, E)) for n in names("mlp_{}/wo/kernel")])
+      if cfg.use_post_attn_norm:
+        m.pan = arr([(n, (E,)) for n in names("post_self_attention_norm_{}/scale")])
+      if cfg.use_post_ffw_norm:
+        m.pfn = arr([(n, (E,)) for n in names("post_ffw_norm_{}/scale")])
+      m.block = 1
+      m.attn_cap = float(cfg.attn_logits_soft_cap or 0.0)
+      m.final_cap = float(cfg.final_logits_soft_cap or 0.0) if cfg.logits_via_embedding else 0.0   # decoders.py:552-565: inside the tied branch
+      m.window = int(cfg.sliding_window_size or 0)
+      m.norm_logits = 1 if (cfg.logits_via_embedding and cfg.normalize_embedding_logits) else 0
+    else:
+      m.ln1 = arr([(lp % i + "pre_self_attention_layer_norm/scale", (E,)) for i in range(L)])
+      m.wq = arr([(lp % i + "self_attention/query/kernel", (E, Q, D)) for i in range(L)])
+      m.wk = arr([(lp % i + "self_attention/key/kernel", (E, KV, D)) for i in range(L)])
+      m.wv = arr([(lp % i + "self_attention/value/kernel", (E, KV, D)) for i in range(L)])
+      m.wo = arr([(lp % i + "self_attention/out/kernel", (Q, D, E)) for i in range(L)])
+      m.ln2 = arr([(lp % i + "mlp/mlp_layer_norm/scale", (E,)) for i in range(L)])
+      m.wi0 = arr([(lp % i + "mlp/wi_0/kernel", (E, F)) for i in range(L)])
+      m.wi1 = arr([(lp % i + "mlp/wi_1/kernel", (E, F)) for i in range(L)])
+      m.wout = arr([(lp % i + "mlp/wo/kernel", (F, E)) for i in range(L)])
     self.rope_sin, self.rope_cos = rope_tables(D, cfg.max_target_length, cfg.rope_min_timescale, cfg.rope_max_timescale)
     m.rope_sin, m.rope_cos = _p(self.rope_sin, _u16p), _p(self.rope_cos, _u16p)
     n = L * cfg.pagedattn_num_pages * cfg.pagedattn_tokens_per_page * KV * D

@@ -61,7 +61,7 @@ def _run_pair(cfg, eng, params, orc, prompts, steps, check_logits, chunks):
   # K/V parity after prefill, every layer
   for slot, (toks, tl) in enumerate(prompts):
     n = int(prefixes[slot]["next_pos"][0, 0])
-    for layer in range(cfg.num_decoder_layers):
+    for layer in range(H.sublayers(cfg)):
       kg, vg = eng.gather_kv(layer, slot, n)
       ko, vo = orc.model.gather_kv(layer, orc.page_state.page_map[slot], n)
       assert np.array_equal(H.bits(kg), ko), (slot, layer)
@@ -87,8 +87,8 @@ def _run_pair(cfg, eng, params, orc, prompts, steps, check_logits, chunks):
   assert np.array_equal(ds["generated_tokens"].cpu().numpy(), ods["generated_tokens"])
   for slot, _ in enumerate(prompts):
     n = int(ods["next_pos"][slot, 0])
-    kg, vg = eng.gather_kv(cfg.num_decoder_layers - 1, slot, n)
-    ko, vo = orc.model.gather_kv(cfg.num_decoder_layers - 1, orc.page_state.page_map[slot], n)
+    kg, vg = eng.gather_kv(H.sublayers(cfg) - 1, slot, n)
+    ko, vo = orc.model.gather_kv(H.sublayers(cfg) - 1, orc.page_state.page_map[slot], n)
     assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo)
   del eng
   torch.cuda.synchronize()
