@@ -148,7 +148,8 @@ static void host_rope_tables(const ixt_config& cfg, std::vector<uint16_t>& sn, s
 extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
   const ixt_config& c = *cfg;
-  if (c.head_dim != 64 && c.head_dim != 128) return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 or 128 built)", c.head_dim);
+  if (c.head_dim != 64 && c.head_dim != 128 && !(c.head_dim == 256 && c.decoder_block == IXT_BLOCK_GEMMA2))
+    return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 and 128 built; 256 for decoder_block gemma2)", c.head_dim);
   if (c.decoder_block != IXT_BLOCK_LLAMA2 && c.decoder_block != IXT_BLOCK_GEMMA2) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2 and gemma2 built)", c.decoder_block);
   const bool gemma = c.decoder_block == IXT_BLOCK_GEMMA2;
   if (!gemma && (c.attn_logits_soft_cap != 0.0f || c.final_logits_soft_cap != 0.0f || c.sliding_window_size != 0 || c.use_post_attn_norm || c.use_post_ffw_norm ||
@@ -856,7 +857,7 @@ static void launch_attn(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t
 
 static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf16_t* qbuf, bf16_t* out, hipStream_t st) {
 #define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn<HD_, GQ_>(c, layer, R, len_hint, qbuf, out, st); LAUNCHCHK(); return IXT_OK; }
-  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4) ATT(256, 1) ATT(256, 2) ATT(256, 4)
 #undef ATT
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
@@ -1004,7 +1005,7 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
     LAUNCHCHK();                                                                                  \
     return IXT_OK;                                                                                \
   }
-  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4) ATT(256, 1) ATT(256, 2) ATT(256, 4)
 #undef ATT
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }

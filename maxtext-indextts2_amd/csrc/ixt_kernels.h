@@ -731,42 +731,43 @@ struct QkvArgs {
 };
 
 __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
-  const int r = blockIdx.x, hh = blockIdx.y, i = threadIdx.x;
+  const int r = blockIdx.x, hh = blockIdx.y;
   const AttnGeom& g = a.g;
   const int half = g.hd / 2;
-  if (i >= half) return;
   const int col0 = hh * g.hd;
   const float* pq = a.part + (size_t)r * a.ncols + col0;
   const bool is_v = hh >= g.nq + g.nkv;
-  float v1 = rbf(sum_slices<16>(pq + (is_v ? i : qk_col(i, half)), a.slice_stride, a.slices));
-  float v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
   const int pos = a.row_pos[r];
-  if (!is_v) {
-    const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
-    const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
-    const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
-    const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
-    v1 = o1;
-    v2 = o2;
-  }
-  if (hh < g.nq) {
-    bf16_t* q = a.qbuf + ((size_t)r * g.nq + hh) * g.hd;
-    q[i] = f2bf(v1);
-    q[half + i] = f2bf(v2);
-    return;
-  }
-  if (!a.row_active[r]) return;
-  const int page = a.page_map[(size_t)a.row_slot[r] * g.mpg + pos / g.P];
-  const int tok = pos % g.P;
-  if (!is_v) {
-    const int kvh = hh - g.nq;
-    a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
-    a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
-  } else {
-    const int kvh = hh - g.nq - g.nkv;
-    bf16_t* v = a.vpages + vpage_off(g, page, kvh, tok);
-    v[i] = f2bf(v1);
-    v[half + i] = f2bf(v2);
+  for (int i = threadIdx.x; i < half; i += 64) {   // head_dim 256: two RoPE pairs per lane
+    float v1 = rbf(sum_slices<16>(pq + (is_v ? i : qk_col(i, half)), a.slice_stride, a.slices));
+    float v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
+    if (!is_v) {
+      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
+      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
+      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
+      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      v1 = o1;
+      v2 = o2;
+    }
+    if (hh < g.nq) {
+      bf16_t* q = a.qbuf + ((size_t)r * g.nq + hh) * g.hd;
+      q[i] = f2bf(v1);
+      q[half + i] = f2bf(v2);
+      continue;
+    }
+    if (!a.row_active[r]) continue;
+    const int page = a.page_map[(size_t)a.row_slot[r] * g.mpg + pos / g.P];
+    const int tok = pos % g.P;
+    if (!is_v) {
+      const int kvh = hh - g.nq;
+      a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
+      a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+    } else {
+      const int kvh = hh - g.nq - g.nkv;
+      bf16_t* v = a.vpages + vpage_off(g, page, kvh, tok);
+      v[i] = f2bf(v1);
+      v[half + i] = f2bf(v2);
+    }
   }
 }
 
@@ -984,8 +985,10 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
   float* psum = sm + (size_t)g.mpg * g.P; // [mpg]
   float* wred = psum + g.mpg;             // [8]
   const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
-  constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
-  constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128, 8 for hd 64)
+  constexpr int FPL = HD > 128 ? 16 : 8;  // features per lane: FPL/8 consecutive 16-byte d-chunks
+  constexpr int NCH = FPL / 8;
+  constexpr int LPP = HD / FPL;           // lanes per page
+  constexpr int PPW = 64 / LPP;           // pages a wave covers at once (4 for hd 128 and 256, 8 for hd 64)
   const int j0 = chunk * 4 * IXT_SB * g.P;  // first key of this block's range
   const int j1 = min(kv_len, j0 + 4 * IXT_SB * g.P);
   const int jvis = (a.window > 0 && kv_len > a.window) ? kv_len - a.window : 0;   // first visible key
@@ -1026,27 +1029,34 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
     if (wave * PPW < 4 * IXT_SB) {
       const int pg_local = wave * PPW + tq;  // 0..15: page within this block's 16-page range
       const int p = chunk * 4 * IXT_SB + pg_local;
-      float acc[8];
+      float acc[FPL];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] = 0.0f;
+      for (int j = 0; j < FPL; ++j) acc[j] = 0.0f;
       if (p < pages) {
         const int page = prow[p];
-        const bf16_t* vp = a.vpages + vpage_off(g, page, kvh, 0) + dc * 8;
+        const bf16_t* vp = a.vpages + vpage_off(g, page, kvh, 0) + dc * FPL;
         const int ntok = min(g.P, kv_len - p * g.P);
         const float* pj = ebuf + (size_t)p * g.P;
         for (int t0 = 0; t0 < ntok; t0 += 8) {
-          u32x4 vv[8];
+          u32x4 vv[8][NCH];
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            vv[u] = (t0 + u < ntok) ? *reinterpret_cast<const u32x4*>(vp + (size_t)(t0 + u) * HD) : u32x4(0);
+#pragma unroll
+            for (int cch = 0; cch < NCH; ++cch)
+              vv[u][cch] = (t0 + u < ntok) ? *reinterpret_cast<const u32x4*>(vp + (size_t)(t0 + u) * HD + cch * 8) : u32x4(0);
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
             if (t0 + u < ntok) {
               const float pv = pj[t0 + u];
-              acc[0] = __builtin_fmaf(pv, bflo(vv[u].x), acc[0]); acc[1] = __builtin_fmaf(pv, bfhi(vv[u].x), acc[1]);
-              acc[2] = __builtin_fmaf(pv, bflo(vv[u].y), acc[2]); acc[3] = __builtin_fmaf(pv, bfhi(vv[u].y), acc[3]);
-              acc[4] = __builtin_fmaf(pv, bflo(vv[u].z), acc[4]); acc[5] = __builtin_fmaf(pv, bfhi(vv[u].z), acc[5]);
-              acc[6] = __builtin_fmaf(pv, bflo(vv[u].w), acc[6]); acc[7] = __builtin_fmaf(pv, bfhi(vv[u].w), acc[7]);
+#pragma unroll
+              for (int cch = 0; cch < NCH; ++cch) {
+                float* ac = acc + cch * 8;
+                const u32x4 w = vv[u][cch];
+                ac[0] = __builtin_fmaf(pv, bflo(w.x), ac[0]); ac[1] = __builtin_fmaf(pv, bfhi(w.x), ac[1]);
+                ac[2] = __builtin_fmaf(pv, bflo(w.y), ac[2]); ac[3] = __builtin_fmaf(pv, bfhi(w.y), ac[3]);
+                ac[4] = __builtin_fmaf(pv, bflo(w.z), ac[4]); ac[5] = __builtin_fmaf(pv, bfhi(w.z), ac[5]);
+                ac[6] = __builtin_fmaf(pv, bflo(w.w), ac[6]); ac[7] = __builtin_fmaf(pv, bfhi(w.w), ac[7]);
+              }
             }
           }
         }
@@ -1054,20 +1064,20 @@ __global__ __launch_bounds__(256) void k_attn_pv(PvArgs a) {
       // super-block sum: pages 4s..4s+3 live in lane groups tq = 4s'..4s'+3 of this wave
       const int sbl = tq / IXT_SB;            // super-block within the wave
       const int base_lane = sbl * IXT_SB * LPP + dc;
-      float sbs[8];
+      float sbs[FPL];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) sbs[j] = 0.0f;
+      for (int j = 0; j < FPL; ++j) sbs[j] = 0.0f;
 #pragma unroll
       for (int i = 0; i < IXT_SB; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) sbs[j] = sbs[j] + __shfl(acc[j], base_lane + i * LPP, 64);
+        for (int j = 0; j < FPL; ++j) sbs[j] = sbs[j] + __shfl(acc[j], base_lane + i * LPP, 64);
       }
       if (tq % IXT_SB == 0) {
         const int sb = chunk * 4 + (wave * PPW) / IXT_SB + sbl;
         if (sb < nsb) {
-          float* dst = a.pvpart + (((size_t)r * g.nq + h) * g.nsb_max + sb) * HD + dc * 8;
-          *reinterpret_cast<float4*>(dst) = make_float4(sbs[0], sbs[1], sbs[2], sbs[3]);
-          *reinterpret_cast<float4*>(dst + 4) = make_float4(sbs[4], sbs[5], sbs[6], sbs[7]);
+          float* dst = a.pvpart + (((size_t)r * g.nq + h) * g.nsb_max + sb) * HD + dc * FPL;
+#pragma unroll
+          for (int j = 0; j < FPL; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(sbs[j], sbs[j + 1], sbs[j + 2], sbs[j + 3]);
         }
       }
     }

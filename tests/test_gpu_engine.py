@@ -260,13 +260,17 @@ def test_tiny_packed_prefill(nprompts, hi):
   """prefill_concat (maxengine.py:719-836) + insert_partial (:1206-1318) over pages: several prompts in ONE pass over the weights, their
   pages handed to permuted slots.  98 rows (split-K dots), 211 rows and 150 rows of 24 prompts (LDS-ring GEMMs with every fused epilogue).
   First tokens, f32 logits, the K/V of every layer, the per-slot page-state fields and the following decode steps equal the oracle's."""
+  packed_prefill_pair(nprompts, hi)
+
+
+def packed_prefill_pair(nprompts, hi, model_name="ixt-tiny", **cfg_kw):
   import torch
   B = nprompts + 2
   rng = np.random.default_rng(nprompts)
   lens = rng.integers(1, hi + 1, size=nprompts)
   lens[0] = hi
-  cfg = H.make_config(per_device_batch_size=float(B), pagedattn_num_pages=2 * B * 16 + 1, ixt_staging_groups=nprompts,
-                      ixt_max_packed_rows=int(lens.sum()))
+  cfg = H.make_config(model_name, per_device_batch_size=float(B), pagedattn_num_pages=2 * B * 16 + 1, ixt_staging_groups=nprompts,
+                      ixt_max_packed_rows=int(lens.sum()), **cfg_kw)
   w = H.synth.synth_weights(cfg, 9)
   eng, params = H.make_engine(cfg, w)
   orc = H.make_oracle(cfg, w)
@@ -288,7 +292,7 @@ def test_tiny_packed_prefill(nprompts, hi):
     assert np.array_equal(st[f], getattr(orc.page_state, f)), f
   assert int(st["page_status"].sum()) == int(orc.page_state.page_status.sum())     # the staging groups kept nothing
   for i, s in enumerate(slots):
-    for layer in range(cfg.num_decoder_layers):
+    for layer in range(H.sublayers(cfg)):
       kg, vg = eng.gather_kv(layer, s, int(lens[i]))
       ko, vo = orc.model.gather_kv(layer, orc.page_state.page_map[s], int(lens[i]))
       assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo), (s, layer)

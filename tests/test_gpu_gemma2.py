@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 import helpers as H
-from test_gpu_engine import run_pair
+from test_gpu_engine import packed_prefill_pair, run_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -88,8 +88,34 @@ def test_gemma2_many_rows_ring_gemm_shapes():
   run_pair(cfg, w, prompts, steps=3, check_logits=False)
 
 
-def test_gemma2_2b_geometry_is_refused_with_a_reason():
-  cfg = H.make_config("gemma2-2b", max_prefill_predict_length=16, max_target_length=32)
+@pytest.mark.parametrize("nprompts,hi", [(6, 32), (24, 12)])
+def test_gemma2_packed_prefill(nprompts, hi):
+  """prefill_concat + insert_partial with the Gemma-2 block: several prompts in one ragged pass (98 rows: split-K dots; 150 rows: ring GEMMs),
+  window 24 shorter than the longest prompt."""
+  packed_prefill_pair(nprompts, hi, model_name="gemma2-tiny")
+
+
+def test_gemma2_head_dim_256_tiny():
+  """head_dim 256 (gemma2-2b's): two RoPE pairs per lane in k_qkv_finalize, 16 features per lane in the PV kernel."""
+  cfg = _cfg(head_dim=256, per_device_batch_size=3.0, pagedattn_num_pages=96)
+  w = H.synth.synth_weights(cfg, 8)
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, 48, 60 + s)[0], [45, 8, 26][s]) for s in range(3)]
+  run_pair(cfg, w, prompts, steps=30)
+
+
+def test_gemma2_2b_widths():
+  """The widths of configs/models/gemma2-2b.yml (emb 2304, 8 x 256 query heads over 4 kv heads, mlp 9216, vocab 256128, tied head, caps 50 / 30)
+  with 2 of its 13 merged layers: every projection shape, the 256 128-column unembedding of the transposed table and head_dim 256 at 2 query heads
+  per kv head against the oracle."""
+  cfg = H.make_config("gemma2-2b", base_num_decoder_layers=2, max_prefill_predict_length=32, max_target_length=64, per_device_batch_size=2.0,
+                      pagedattn_num_pages=40, sliding_window_size=20)
+  w = H.synth.synth_weights(cfg, 10)
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, 32, 80 + s)[0], [27, 6][s]) for s in range(2)]
+  run_pair(cfg, w, prompts, steps=5)
+
+
+def test_head_dim_256_needs_the_gemma2_block():
+  cfg = H.make_config(head_dim=256, max_prefill_predict_length=16, max_target_length=32)
   maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
   with pytest.raises(Exception, match="head_dim 256"):
     maxengine.MaxEngine(cfg)
