@@ -56,8 +56,8 @@ typedef struct ixt_config {
    * IXT_BLOCK_GEMMA2 (layers/gemma2.py:69-236, configs/models/gemma2-2b.yml): `num_decoder_layers` counts the reference's merged
    * [local, global] layers; the context then holds 2 x num_decoder_layers (attention, MLP) sub-layers -- sub-layer 2 i is layer i's
    * "local" half, 2 i + 1 its "global" half -- and every `layer` argument of this header (ixt_kv_gather, ixt_op_kv_write,
-   * ixt_op_paged_attention) indexes sub-layers.  The fields below are read for gemma2 only and must be zero otherwise. */
-  int32_t decoder_block;           /* base.yml decoder_block: IXT_BLOCK_LLAMA2 | IXT_BLOCK_GEMMA2 */
+   * ixt_op_paged_attention) indexes sub-layers.  The fields below are read for gemma2 / gemma3 only and must be zero otherwise. */
+  int32_t decoder_block;           /* base.yml decoder_block: IXT_BLOCK_LLAMA2 | IXT_BLOCK_GEMMA2 | IXT_BLOCK_GEMMA3 */
   float attn_logits_soft_cap;      /* attentions.py:1257-1259: score = tanh(score / cap) * cap in f32 before the softmax; 0 = none */
   float final_logits_soft_cap;     /* decoders.py:563-565 (inside the logits_via_embedding branch, as in the reference); 0 = none */
   int32_t sliding_window_size;     /* attentions.py:625-631, local sub-layers: key j visible iff pos - window < j <= pos; 0 = none */
@@ -65,9 +65,15 @@ typedef struct ixt_config {
   int32_t use_post_ffw_norm;       /* gemma2.py:135-143, :227-235: RMSNorm of the MLP output before the residual add */
   int32_t logits_via_embedding;    /* decoders.py:552-558: logits = y . embedding^T (no logits_dense kernel is loaded) */
   int32_t normalize_embedding_logits; /* decoders.py:560-562: logits / sqrt(emb_dim), in f32 (the divisor is an f32 array) */
+  /* IXT_BLOCK_GEMMA3 (layers/gemma3.py:35-200, configs/models/gemma3-4b.yml): one (attention, MLP) pair per layer with the Gemma-2 fields
+   * above (post norms, GELU gate, caps, tied head); layer i is local sliding unless i % 6 == 5 (GEMMA3_ATTENTION_PATTERN, gemma3.py:35-47);
+   * every query / key head is RMS-normalised over head_dim before RoPE (`self_attention/{query,key}_norm/scale`, attentions.py:1872-1888,
+   * :2246-2248).  Read for gemma3 only: */
+  float local_rope_max_timescale;  /* base.yml:603, attentions.py:2085-2088: RoPE base of the local layers; <= 0: rope_max_timescale */
+  float query_pre_attn_scalar;     /* gemma3.py:50-58, attentions.py:2262-2264: q = bf16(q * bf16(scalar)) after RoPE; 0 or 1: none */
 } ixt_config;
 
-enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1 };
+enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2 };
 
 typedef struct ixt_ctx ixt_ctx;
 

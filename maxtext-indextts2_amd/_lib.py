@@ -33,9 +33,10 @@ class IxtConfig(ctypes.Structure):
       ("decoder_block", ctypes.c_int32), ("attn_logits_soft_cap", ctypes.c_float), ("final_logits_soft_cap", ctypes.c_float),
       ("sliding_window_size", ctypes.c_int32), ("use_post_attn_norm", ctypes.c_int32), ("use_post_ffw_norm", ctypes.c_int32),
       ("logits_via_embedding", ctypes.c_int32), ("normalize_embedding_logits", ctypes.c_int32),
+      ("local_rope_max_timescale", ctypes.c_float), ("query_pre_attn_scalar", ctypes.c_float),
   ]
 
-BLOCK_LLAMA2, BLOCK_GEMMA2 = 0, 1
+BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3 = 0, 1, 2
 
 
 # name -> (restype, argtypes); every symbol include/ixt.h declares

@@ -34,10 +34,11 @@ extern "C" const char* ixt_last_error(void) { return g_err; }
 
 struct LayerW {
   bf16_t *ln1, *wqkv, *wo, *ln2, *wi, *wout;
-  bf16_t *pan = nullptr, *pfn = nullptr;   // Gemma-2: post-attention / post-MLP norm scales
+  bf16_t *pan = nullptr, *pfn = nullptr;   // Gemma-2 / 3: post-attention / post-MLP norm scales
+  bf16_t *qn = nullptr, *kn = nullptr;     // Gemma-3: query / key head norm scales [head_dim]
 };
 
-enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER, W_PAN = W_PER_LAYER, W_PFN };
+enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER, W_PAN = W_PER_LAYER, W_PFN, W_QN, W_KN };
 
 struct TimingPair { hipEvent_t a, b; double bytes; int family; };   // family: 0 canonical dot (incl. unembedding), 1 one-launch decode attention
 
@@ -58,6 +59,7 @@ struct ixt_ctx {
   std::vector<uint32_t> loaded;  // per layer bitmask; index L = globals (bit0 emb, bit1 norm, bit2 logits)
   // tables / pools / state
   bf16_t *rope_sin = nullptr, *rope_cos = nullptr;
+  bf16_t *rope_sin_local = nullptr, *rope_cos_local = nullptr;   // Gemma-3 local layers (local_rope_max_timescale); nullptr: the tables above
   std::vector<uint16_t> rope_sin_h, rope_cos_h;
   std::vector<bf16_t*> kpages_l, vpages_l;   // one allocation per layer: [page][kv_head][...]
   bf16_t **kptrs_d = nullptr, **vptrs_d = nullptr;   // the same pointers in HBM (k_pages_copy)
@@ -99,6 +101,7 @@ struct ixt_ctx {
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   // Gemma-2 block (ixt_config.decoder_block == 1): L counts (attention, MLP) sub-layers, two per reference layer (even: local sliding)
   bool gemma = false;
+  bool gemma3 = false;       // Gemma-3 (decoder_block == 2): gemma = true as well; one sub-layer per layer, layer l local unless l % 6 == 5
   float pv_cap = 0.0f;       // soft cap / window of the attention launch being issued (k_attn_pv)
   int pv_window = 0;
   float* glogits = nullptr;  // [NLmax][V] logits rows when the caller asks for none (the cap and the sampling need them)
@@ -122,7 +125,15 @@ static int dmalloc(ixt_ctx* c, T** p, size_t n) {
 
 static bool is_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 
-static void host_rope_tables(const ixt_config& cfg, std::vector<uint16_t>& sn, std::vector<uint16_t>& cs) {
+static float host_rbf(float f) {
+  uint32_t u; memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+static void host_rope_tables(const ixt_config& cfg, float max_timescale, std::vector<uint16_t>& sn, std::vector<uint16_t>& cs) {
   // embeddings.py:270-307; every step's rounding is listed in DESIGN.md section 3.
   const int half = cfg.head_dim / 2, T = cfg.max_target_length;
   sn.resize((size_t)T * half);
@@ -135,7 +146,7 @@ static void host_rope_tables(const ixt_config& cfg, std::vector<uint16_t>& sn, s
   std::vector<float> ts(half);
   for (int i = 0; i < half; ++i) {
     const float frac = (float)(2 * i) / (float)cfg.head_dim;
-    ts[i] = (float)((double)cfg.rope_min_timescale * pow((double)cfg.rope_max_timescale / (double)cfg.rope_min_timescale, (double)frac));
+    ts[i] = (float)((double)cfg.rope_min_timescale * pow((double)max_timescale / (double)cfg.rope_min_timescale, (double)frac));
   }
   for (int p = 0; p < T; ++p)
     for (int i = 0; i < half; ++i) {
@@ -148,13 +159,17 @@ static void host_rope_tables(const ixt_config& cfg, std::vector<uint16_t>& sn, s
 extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
   const ixt_config& c = *cfg;
-  if (c.head_dim != 64 && c.head_dim != 128 && !(c.head_dim == 256 && c.decoder_block == IXT_BLOCK_GEMMA2))
-    return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 and 128 built; 256 for decoder_block gemma2)", c.head_dim);
-  if (c.decoder_block != IXT_BLOCK_LLAMA2 && c.decoder_block != IXT_BLOCK_GEMMA2) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2 and gemma2 built)", c.decoder_block);
-  const bool gemma = c.decoder_block == IXT_BLOCK_GEMMA2;
+  const bool gemma3 = c.decoder_block == IXT_BLOCK_GEMMA3;
+  const bool gemma = c.decoder_block == IXT_BLOCK_GEMMA2 || gemma3;
+  if (c.head_dim != 64 && c.head_dim != 128 && !(c.head_dim == 256 && gemma))
+    return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 and 128 built; 256 for decoder_block gemma2 / gemma3)", c.head_dim);
+  if (c.decoder_block != IXT_BLOCK_LLAMA2 && !gemma) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2, gemma2 and gemma3 built)", c.decoder_block);
+  if (!gemma3 && (c.local_rope_max_timescale != 0.0f || c.query_pre_attn_scalar != 0.0f))
+    return set_err(IXT_ERR_UNSUPPORTED, "local_rope_max_timescale and query_pre_attn_scalar are read for decoder_block gemma3 only");
+  if (c.query_pre_attn_scalar < 0.0f) return set_err(IXT_ERR_INVALID, "negative query_pre_attn_scalar");
   if (!gemma && (c.attn_logits_soft_cap != 0.0f || c.final_logits_soft_cap != 0.0f || c.sliding_window_size != 0 || c.use_post_attn_norm || c.use_post_ffw_norm ||
                  c.logits_via_embedding))
-    return set_err(IXT_ERR_UNSUPPORTED, "soft caps, sliding window, post norms and the tied head are built for decoder_block gemma2 only");
+    return set_err(IXT_ERR_UNSUPPORTED, "soft caps, sliding window, post norms and the tied head are built for decoder_block gemma2 / gemma3 only");
   if (c.attn_logits_soft_cap < 0.0f || c.final_logits_soft_cap < 0.0f || c.sliding_window_size < 0) return set_err(IXT_ERR_INVALID, "negative soft cap or window");
   if (c.emb_dim % IXT_KALIGN || c.mlp_dim % IXT_KALIGN || (c.num_query_heads * c.head_dim) % IXT_KALIGN)
     return set_err(IXT_ERR_UNSUPPORTED, "emb_dim, mlp_dim and num_query_heads*head_dim must be multiples of %d", IXT_KALIGN);
@@ -178,7 +193,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   ixt_ctx* x = new ixt_ctx();
   x->cfg = c;
   x->E = c.emb_dim; x->Q = c.num_query_heads; x->KV = c.num_kv_heads; x->D = c.head_dim; x->F = c.mlp_dim;
-  x->V = c.vocab_size; x->L = c.num_decoder_layers * (gemma ? 2 : 1); x->gemma = gemma; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
+  x->V = c.vocab_size; x->L = c.num_decoder_layers * ((gemma && !gemma3) ? 2 : 1); x->gemma = gemma; x->gemma3 = gemma3; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
   x->QN = x->Q * x->D; x->KN = x->KV * x->D; x->NQKV = x->QN + 2 * x->KN; x->Tmax = c.max_target_length;
   x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
   x->nsb_max = (x->mpg + IXT_SB - 1) / IXT_SB;
@@ -207,15 +222,25 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     A(dmalloc(x, &w.wout, (size_t)F * E));
     if (gemma && c.use_post_attn_norm) A(dmalloc(x, &w.pan, (size_t)E));
     if (gemma && c.use_post_ffw_norm) A(dmalloc(x, &w.pfn, (size_t)E));
+    if (gemma3) { A(dmalloc(x, &w.qn, (size_t)x->D)); A(dmalloc(x, &w.kn, (size_t)x->D)); }
   }
   if (gemma) A(dmalloc(x, &x->glogits, (size_t)x->NLmax * V));
   // RoPE tables
-  host_rope_tables(c, x->rope_sin_h, x->rope_cos_h);
+  host_rope_tables(c, c.rope_max_timescale, x->rope_sin_h, x->rope_cos_h);
   A(dmalloc(x, &x->rope_sin, x->rope_sin_h.size()));
   A(dmalloc(x, &x->rope_cos, x->rope_cos_h.size()));
   if (hipMemcpy(x->rope_sin, x->rope_sin_h.data(), x->rope_sin_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(x->rope_cos, x->rope_cos_h.data(), x->rope_cos_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
     return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
+  if (gemma3 && c.local_rope_max_timescale > 0.0f) {   // attentions.py:2085-2088
+    std::vector<uint16_t> sl, cl;
+    host_rope_tables(c, c.local_rope_max_timescale, sl, cl);
+    A(dmalloc(x, &x->rope_sin_local, sl.size()));
+    A(dmalloc(x, &x->rope_cos_local, cl.size()));
+    if (hipMemcpy(x->rope_sin_local, sl.data(), sl.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(x->rope_cos_local, cl.data(), cl.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
+  }
   // page pools
   x->layer_page_elems = (size_t)c.pagedattn_num_pages * x->KV * x->P * x->D;
   x->kpages_l.assign(L, nullptr);
@@ -361,7 +386,15 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
   if (sscanf(p.c_str(), "decoder/layers_%d/%n", &li, &consumed) < 1 || li < 0 || li >= c->L || consumed == 0)
     return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
   std::string rest = p.substr(consumed);
-  if (c->gemma) {
+  if (c->gemma3) {
+    // layers/gemma3.py:83-200: llama2's spellings except the attention pre-norm; the post norms and the head norms are Gemma's own
+    if (rest == "pre_self_attention_norm/scale") rest = "pre_self_attention_layer_norm/scale";
+    LayerW& gw = c->layers[li];
+    if (rest == "post_self_attention_norm/scale" && gw.pan) { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, gw.pan, 1, E, E, st)); c->loaded[li] |= 1u << W_PAN; return IXT_OK; }
+    if (rest == "post_ffw_norm/scale" && gw.pfn) { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, gw.pfn, 1, E, E, st)); c->loaded[li] |= 1u << W_PFN; return IXT_OK; }
+    if (rest == "self_attention/query_norm/scale") { TRY(expect(c->D)); TRY(copy_param(dev_ptr, dtype, gw.qn, 1, c->D, c->D, st)); c->loaded[li] |= 1u << W_QN; return IXT_OK; }
+    if (rest == "self_attention/key_norm/scale") { TRY(expect(c->D)); TRY(copy_param(dev_ptr, dtype, gw.kn, 1, c->D, c->D, st)); c->loaded[li] |= 1u << W_KN; return IXT_OK; }
+  } else if (c->gemma) {
     // layers/gemma2.py:69-236: reference layer li holds a "local" and a "global" (attention, MLP) pair = sub-layers 2 li and 2 li + 1.
     // The names are mapped onto the llama2 spellings below; the post norms are Gemma's own.
     if (li >= c->L / 2) return set_err(IXT_ERR_INVALID, "unknown parameter path %s", path);
@@ -405,6 +438,7 @@ extern "C" int ixt_weights_complete(ixt_ctx* c) {
     uint32_t want = (1u << W_PER_LAYER) - 1;
     if (c->layers[i].pan) want |= 1u << W_PAN;
     if (c->layers[i].pfn) want |= 1u << W_PFN;
+    if (c->layers[i].qn) want |= (1u << W_QN) | (1u << W_KN);
     if (c->loaded[i] != want) return 0;
   }
   return c->loaded[c->L] == 7 ? 1 : 0;
@@ -1033,13 +1067,18 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
     QkvArgs qa;
     qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
     qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
-    qa.rope_sin = c->rope_sin; qa.rope_cos = c->rope_cos; qa.qbuf = c->qbuf;
+    // gemma2.py: even sub-layers are the local ones; gemma3.py:35-47: five local layers, then a global one
+    const bool local = c->gemma3 ? (l % 6 != 5) : (l % 2 == 0);
+    const bool lrope = local && c->rope_sin_local != nullptr;
+    qa.rope_sin = lrope ? c->rope_sin_local : c->rope_sin; qa.rope_cos = lrope ? c->rope_cos_local : c->rope_cos; qa.qbuf = c->qbuf;
     qa.kpages = c->kpages_l[l]; qa.vpages = c->vpages_l[l];
     qa.g = c->geom;
+    qa.qnorm = w.qn; qa.knorm = w.kn; qa.eps = cf.normalization_layer_epsilon;
+    qa.q_scalar = (cf.query_pre_attn_scalar != 0.0f && cf.query_pre_attn_scalar != 1.0f) ? host_rbf(cf.query_pre_attn_scalar) : 0.0f;
     hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
     LAUNCHCHK();
     c->pv_cap = cf.attn_logits_soft_cap;
-    c->pv_window = (l % 2 == 0) ? cf.sliding_window_size : 0;
+    c->pv_window = local ? cf.sliding_window_size : 0;
     int rc = launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st);
     c->pv_cap = 0.0f; c->pv_window = 0;
     TRY(rc);

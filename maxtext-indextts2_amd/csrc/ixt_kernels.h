@@ -728,6 +728,10 @@ struct QkvArgs {
   bf16_t* qbuf;                                     // [R][nq][hd]
   bf16_t* kpages; bf16_t* vpages;                   // this layer's pools
   AttnGeom g;
+  // Gemma-3 (attentions.py:2246-2248, :2262-2264): RMSNorm over head_dim of every query / key head before RoPE (scales [hd]; nullptr:
+  // none) and q * q_scalar (a bf16 value) after it (0: none)
+  const bf16_t* qnorm = nullptr; const bf16_t* knorm = nullptr;
+  float eps = 0.0f, q_scalar = 0.0f;
 };
 
 __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
@@ -738,9 +742,40 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
   const float* pq = a.part + (size_t)r * a.ncols + col0;
   const bool is_v = hh >= g.nq + g.nkv;
   const int pos = a.row_pos[r];
+  // head norm (block-uniform): the head's bf16 values in feature order -> LDS; sum of squares in the RMSNorm order (lane = chunk of 8
+  // features by fma, xor tree over the wave; head_dim <= 512 is one block)
+  const bf16_t* nscale = is_v ? nullptr : (hh < g.nq ? a.qnorm : a.knorm);
+  __shared__ float hv[512];
+  float nr = 0.0f;
+  if (nscale != nullptr) {
+    for (int i = threadIdx.x; i < half; i += 64) {
+      hv[i] = rbf(sum_slices<16>(pq + qk_col(i, half), a.slice_stride, a.slices));
+      hv[half + i] = rbf(sum_slices<16>(pq + qk_col(half + i, half), a.slice_stride, a.slices));
+    }
+    __syncthreads();
+    float ss = 0.0f;
+    if ((int)threadIdx.x < g.hd / 8) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = hv[threadIdx.x * 8 + j];
+        ss = __builtin_fmaf(x, x, ss);
+      }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) ss = ss + __shfl_xor(ss, off, 64);
+    const float total = 0.0f + ss;
+    nr = 1.0f / sqrtf(total / (float)g.hd + a.eps);
+  }
+  const float qs = (hh < g.nq && a.q_scalar != 0.0f) ? a.q_scalar : 0.0f;
   for (int i = threadIdx.x; i < half; i += 64) {   // head_dim 256: two RoPE pairs per lane
-    float v1 = rbf(sum_slices<16>(pq + (is_v ? i : qk_col(i, half)), a.slice_stride, a.slices));
-    float v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
+    float v1, v2;
+    if (nscale != nullptr) {
+      v1 = rbf(rbf(hv[i] * nr) * bf2f(nscale[i]));
+      v2 = rbf(rbf(hv[half + i] * nr) * bf2f(nscale[half + i]));
+    } else {
+      v1 = rbf(sum_slices<16>(pq + (is_v ? i : qk_col(i, half)), a.slice_stride, a.slices));
+      v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
+    }
     if (!is_v) {
       const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
       const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
@@ -748,6 +783,10 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
       const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
       v1 = o1;
       v2 = o2;
+      if (qs != 0.0f) {
+        v1 = rbf(v1 * qs);
+        v2 = rbf(v2 * qs);
+      }
     }
     if (hh < g.nq) {
       bf16_t* q = a.qbuf + ((size_t)r * g.nq + hh) * g.hd;

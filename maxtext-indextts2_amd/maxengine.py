@@ -54,6 +54,16 @@ def _stream_ptr() -> int:
   return torch.cuda.current_stream().cuda_stream
 
 
+def get_query_pre_attn_scalar(config) -> float:
+  """layers/gemma3.py:50-58.  The reference knows three model names; any other gemma3-* name (the small test geometries) takes the
+  4b / 12b rule."""
+  if config.model_name == "gemma3-27b":
+    return (config.base_emb_dim // config.base_num_query_heads) ** -0.5
+  if str(config.model_name).startswith("gemma3"):
+    return config.head_dim ** -0.5
+  raise ValueError(f"Unsupported model name: {config.model_name}")
+
+
 class MaxEngine(engine_api.Engine):
   """See module docstring; reference: maxengine.py:100."""
 
@@ -85,10 +95,13 @@ class MaxEngine(engine_api.Engine):
     c.use_hip_graph = 1 if config.ixt_use_hip_graph else 0
     c.max_packed_rows = int(config.ixt_max_packed_rows)
     c.staging_groups = int(config.ixt_staging_groups)
-    if config.decoder_block == "gemma2":          # layers/gemma2.py:69-236
+    if config.decoder_block in ("gemma2", "gemma3"):   # layers/gemma2.py:69-236, layers/gemma3.py:35-200
       if tuple(config.mlp_activations) != ("gelu", "linear"):
-        raise ValueError("decoder_block gemma2 is built with mlp_activations ['gelu', 'linear']")
-      c.decoder_block = _lib.BLOCK_GEMMA2
+        raise ValueError(f"decoder_block {config.decoder_block} is built with mlp_activations ['gelu', 'linear']")
+      c.decoder_block = _lib.BLOCK_GEMMA2 if config.decoder_block == "gemma2" else _lib.BLOCK_GEMMA3
+      if config.decoder_block == "gemma3":
+        c.local_rope_max_timescale = float(config.local_rope_max_timescale)
+        c.query_pre_attn_scalar = float(get_query_pre_attn_scalar(config))
       c.attn_logits_soft_cap = float(config.attn_logits_soft_cap or 0.0)
       c.final_logits_soft_cap = float(config.final_logits_soft_cap or 0.0)
       c.sliding_window_size = int(config.sliding_window_size or 0)

@@ -140,11 +140,11 @@ def _derive(keys: Dict[str, Any]) -> None:
     keys["pagedattn_max_pages_per_group"] = -(-keys["max_target_length"] // keys["pagedattn_tokens_per_page"])
   if keys["attention"] not in VALID_ATTENTION:
     raise ValueError(f"Invalid attention {keys['attention']}; valid: {VALID_ATTENTION}")
-  if keys["decoder_block"] not in ("llama2", "default", "gemma2"):
-    raise ValueError(f"decoder_block {keys['decoder_block']} is outside this build's hot path (llama2 and gemma2 are built)")
-  if keys["decoder_block"] != "gemma2" and (keys["attn_logits_soft_cap"] or keys["final_logits_soft_cap"] or keys["sliding_window_size"] or
+  if keys["decoder_block"] not in ("llama2", "default", "gemma2", "gemma3"):
+    raise ValueError(f"decoder_block {keys['decoder_block']} is outside this build's hot path (llama2, gemma2 and gemma3 are built)")
+  if keys["decoder_block"] not in ("gemma2", "gemma3") and (keys["attn_logits_soft_cap"] or keys["final_logits_soft_cap"] or keys["sliding_window_size"] or
                                             keys["use_post_attn_norm"] or keys["use_post_ffw_norm"] or keys["logits_via_embedding"]):
-    raise ValueError("soft caps, sliding_window_size, post norms and logits_via_embedding are built for decoder_block gemma2 only")
+    raise ValueError("soft caps, sliding_window_size, post norms and logits_via_embedding are built for decoder_block gemma2 / gemma3 only")
   if isinstance(keys["mlp_activations"], list):
     keys["mlp_activations"] = tuple(keys["mlp_activations"])
 

@@ -109,10 +109,60 @@ def synth_weights_gemma2(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
   return w
 
 
+def gemma3_layer_paths(i: int):
+  """layers/gemma3.py:83-200 parameter names of layer i (query / key norms: attentions.py:1872-1888)."""
+  p = f"params/decoder/layers_{i}/"
+  d = layer_paths(i)
+  d.update({
+      "ln1": p + "pre_self_attention_norm/scale",
+      "qn": p + "self_attention/query_norm/scale",
+      "kn": p + "self_attention/key_norm/scale",
+      "pan": p + "post_self_attention_norm/scale",
+      "pfn": p + "post_ffw_norm/scale",
+  })
+  return d
+
+
+def synth_weights_gemma3(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+  """Random Gemma-3 tree; every norm scale (also the per-head query / key norms) is drawn around 1."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
+                          cfg.num_decoder_layers)
+
+  def scale(n=E):
+    return f32_to_bf16_bits(1.0 + 0.25 * rng.standard_normal(n, dtype=np.float32))
+
+  w: Dict[str, np.ndarray] = {}
+  w["params/token_embedder/embedding"] = f32_to_bf16_bits(rng.standard_normal(V * E, dtype=np.float32)).reshape(V, E)
+  for i in range(L):
+    p = gemma3_layer_paths(i)
+    w[p["ln1"]] = scale()
+    w[p["q"]] = _dense(rng, (E, Q, D), E, math.sqrt(D))
+    w[p["k"]] = _dense(rng, (E, KV, D), E)
+    w[p["v"]] = _dense(rng, (E, KV, D), E)
+    w[p["o"]] = _dense(rng, (Q, D, E), Q * D)
+    w[p["qn"]] = scale(D)
+    w[p["kn"]] = scale(D)
+    w[p["ln2"]] = scale()
+    w[p["wi0"]] = _dense(rng, (E, F), E)
+    w[p["wi1"]] = _dense(rng, (E, F), E)
+    w[p["wo"]] = _dense(rng, (F, E), F)
+    if getattr(cfg, "use_post_attn_norm", False):
+      w[p["pan"]] = scale()
+    if getattr(cfg, "use_post_ffw_norm", False):
+      w[p["pfn"]] = scale()
+  w["params/decoder/decoder_norm/scale"] = scale()
+  if not getattr(cfg, "logits_via_embedding", False):
+    w["params/decoder/logits_dense/kernel"] = _dense(rng, (E, V), E)
+  return w
+
+
 def synth_weights(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
   """cfg needs vocab_size, emb_dim, num_query_heads, num_kv_heads, head_dim, mlp_dim, num_decoder_layers."""
   if getattr(cfg, "decoder_block", "llama2") == "gemma2":
     return synth_weights_gemma2(cfg, seed)
+  if getattr(cfg, "decoder_block", "llama2") == "gemma3":
+    return synth_weights_gemma3(cfg, seed)
   rng = np.random.Generator(np.random.PCG64(seed))
   E, Q, KV, D, F, V, L = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
                           cfg.num_decoder_layers)

@@ -63,13 +63,20 @@ typedef struct orc_model {
   uint16_t* vpages;
   /* SURVEY.md section 8(f) item 3, Gemma-2 block (layers/gemma2.py:69-236): nlayers then counts (attention, MLP) sub-layers, two per
    * reference layer: even = local sliding window, odd = global.  All zero / NULL: the llama2 block. */
-  int32_t block;                      /* 0 llama2, 1 gemma2 */
+  int32_t block;                      /* 0 llama2, 1 gemma2, 2 gemma3 */
   float attn_cap;                     /* attn_logits_soft_cap (attentions.py:1257-1259), 0: none */
   float final_cap;                    /* final_logits_soft_cap (decoders.py:563-565), 0: none */
   int32_t window;                     /* sliding_window_size of the local sub-layers (attentions.py:625-631), 0: none */
   int32_t norm_logits;                /* normalize_embedding_logits (decoders.py:560-562): logits / sqrt(emb) in f32 */
   const uint16_t* const* pan;         /* [L] -> [emb] post_self_attention_norm, NULL: none */
   const uint16_t* const* pfn;         /* [L] -> [emb] post_ffw_norm, NULL: none */
+  /* Gemma-3 block (block == 2; layers/gemma3.py:35-200): nlayers counts the reference's layers, layer L is local sliding unless
+   * L % 6 == 5 (GEMMA3_ATTENTION_PATTERN, gemma3.py:35-47). */
+  const uint16_t* const* qn;          /* [L] -> [hd] self_attention/query_norm/scale (attentions.py:1872-1888, :2246-2248), NULL: none */
+  const uint16_t* const* kn;          /* [L] -> [hd] self_attention/key_norm/scale */
+  float q_scalar;                     /* query_pre_attn_scalar (gemma3.py:50-58, attentions.py:2262-2264): q * scalar after RoPE; 0 or 1: none */
+  const uint16_t* rope_sin_local;     /* [max_pos][hd/2]: tables of the local layers (local_rope_max_timescale, attentions.py:2085-2088); NULL: rope_sin */
+  const uint16_t* rope_cos_local;
 } orc_model;
 
 /* ---------------------------------------------------------------- scalars */
@@ -611,7 +618,7 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
   int max_len = 0;
   for (int r = 0; r < R; ++r)
     if (pos[r] + 1 > max_len) max_len = pos[r] + 1;
-  const int gemma = m->block == 1;
+  const int gemma = m->block >= 1;
 
   for (int r = 0; r < R; ++r) memcpy(h + (size_t)r * E, m->embedding + (size_t)tokens[r] * E, sizeof(uint16_t) * E);
 
@@ -622,11 +629,22 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
     dot_rows_bf16(xn, E, R, m->wv[L], E, KN, v, KN, scratch);
     uint16_t* kp = m->kpages + (size_t)L * m->num_pages * page_elems;
     uint16_t* vp = m->vpages + (size_t)L * m->num_pages * page_elems;
+    /* gemma2.py: even sub-layers are the local ones; gemma3.py:35-47: five local layers, then a global one */
+    const int local = m->block == 1 ? (L % 2 == 0) : (m->block == 2 ? (L % 6 != 5) : 0);
+    const uint16_t* rsin = (local && m->rope_sin_local) ? m->rope_sin_local : m->rope_sin;
+    const uint16_t* rcos = (local && m->rope_cos_local) ? m->rope_cos_local : m->rope_cos;
+    const float qsc = rbf(m->q_scalar);   /* a weakly typed Python float joins the bf16 array as bf16 */
     for (int r = 0; r < R; ++r) {
-      const uint16_t* sn = m->rope_sin + (size_t)pos[r] * (hd / 2);
-      const uint16_t* cs = m->rope_cos + (size_t)pos[r] * (hd / 2);
+      const uint16_t* sn = rsin + (size_t)pos[r] * (hd / 2);
+      const uint16_t* cs = rcos + (size_t)pos[r] * (hd / 2);
+      if (m->qn)   /* attentions.py:2246-2248: RMSNorm over head_dim of every query / key head, before RoPE */
+        for (int hh = 0; hh < nq; ++hh) orc_rmsnorm(q + (size_t)r * QN + (size_t)hh * hd, m->qn[L], q + (size_t)r * QN + (size_t)hh * hd, hd, m->eps);
+      if (m->kn)
+        for (int hh = 0; hh < nkv; ++hh) orc_rmsnorm(k + (size_t)r * KN + (size_t)hh * hd, m->kn[L], k + (size_t)r * KN + (size_t)hh * hd, hd, m->eps);
       orc_rope(q + (size_t)r * QN, nq, hd, sn, cs);
       orc_rope(k + (size_t)r * KN, nkv, hd, sn, cs);
+      if (m->q_scalar != 0.0f && m->q_scalar != 1.0f)   /* attentions.py:2262-2264 */
+        for (int i = 0; i < QN; ++i) q[(size_t)r * QN + i] = f2bf(bf2f(q[(size_t)r * QN + i]) * qsc);
       if (active[r]) {
         int32_t pg = page_map[(size_t)slot[r] * m->max_pages_per_group + pos[r] / P];
         size_t off = (size_t)pg * page_elems + (size_t)(pos[r] % P) * nkv * hd;
@@ -641,7 +659,7 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
       for (int r = 0; r < R; ++r) {
         int kv_len = active[r] ? pos[r] + 1 : 0;
         orc_attend_row_ex(m, L, q + (size_t)r * QN, page_map + (size_t)slot[r] * m->max_pages_per_group, kv_len,
-                          ao + (size_t)r * QN, sc, gemma ? m->attn_cap : 0.0f, (gemma && L % 2 == 0) ? m->window : 0);
+                          ao + (size_t)r * QN, sc, gemma ? m->attn_cap : 0.0f, local ? m->window : 0);
       }
       free(sc);
     }

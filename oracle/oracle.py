@@ -55,6 +55,7 @@ class _CModel(ctypes.Structure):
       ("kpages", _u16p), ("vpages", _u16p),
       ("block", ctypes.c_int32), ("attn_cap", ctypes.c_float), ("final_cap", ctypes.c_float), ("window", ctypes.c_int32),
       ("norm_logits", ctypes.c_int32), ("pan", _u16pp), ("pfn", _u16pp),
+      ("qn", _u16pp), ("kn", _u16pp), ("q_scalar", ctypes.c_float), ("rope_sin_local", _u16p), ("rope_cos_local", _u16p),
   ]
 
 
@@ -351,6 +352,10 @@ class OracleConfig:
   use_post_ffw_norm: bool = False
   logits_via_embedding: bool = False
   normalize_embedding_logits: bool = True
+  # Gemma-3 block (layers/gemma3.py:35-200; configs/models/gemma3-4b.yml): one (attention, MLP) pair per layer, layer i local unless
+  # i % 6 == 5; query / key RMSNorm over head_dim; q * query_pre_attn_scalar after RoPE; the local layers' own RoPE base
+  local_rope_max_timescale: float = -1.0
+  query_pre_attn_scalar: float = 0.0
 
   @property
   def sublayers(self) -> int:
@@ -371,6 +376,7 @@ class OracleModel:
     self.lib = lib()
     L = cfg.sublayers
     gemma = cfg.decoder_block == "gemma2"
+    gemma3 = cfg.decoder_block == "gemma3"
     self._keep: List[np.ndarray] = []
 
     def w(path, shape):
@@ -395,7 +401,7 @@ class OracleModel:
     m.eps = cfg.normalization_layer_epsilon
     m.embedding = _p(w("params/token_embedder/embedding", (V, E)), _u16p)
     m.final_norm = _p(w("params/decoder/decoder_norm/scale", (E,)), _u16p)
-    if gemma and cfg.logits_via_embedding:   # decoders.py:552-558: the transposed embedding table is the logits kernel
+    if (gemma or gemma3) and cfg.logits_via_embedding:   # decoders.py:552-558: the transposed embedding table is the logits kernel
       tied = np.ascontiguousarray(np.asarray(weights["params/token_embedder/embedding"]).reshape(V, E).T)
       self._keep.append(tied)
       m.logits_w = _p(tied, _u16p)
@@ -427,6 +433,32 @@ class OracleModel:
       m.final_cap = float(cfg.final_logits_soft_cap or 0.0) if cfg.logits_via_embedding else 0.0   # decoders.py:552-565: inside the tied branch
       m.window = int(cfg.sliding_window_size or 0)
       m.norm_logits = 1 if (cfg.logits_via_embedding and cfg.normalize_embedding_logits) else 0
+    elif gemma3:
+      # layers/gemma3.py:83-200 parameter names (the MLP pre-norm lives inside mlp_block: use_pre_norm=True)
+      m.ln1 = arr([(lp % i + "pre_self_attention_norm/scale", (E,)) for i in range(L)])
+      m.wq = arr([(lp % i + "self_attention/query/kernel", (E, Q, D)) for i in range(L)])
+      m.wk = arr([(lp % i + "self_attention/key/kernel", (E, KV, D)) for i in range(L)])
+      m.wv = arr([(lp % i + "self_attention/value/kernel", (E, KV, D)) for i in range(L)])
+      m.wo = arr([(lp % i + "self_attention/out/kernel", (Q, D, E)) for i in range(L)])
+      m.qn = arr([(lp % i + "self_attention/query_norm/scale", (D,)) for i in range(L)])
+      m.kn = arr([(lp % i + "self_attention/key_norm/scale", (D,)) for i in range(L)])
+      m.ln2 = arr([(lp % i + "mlp/mlp_layer_norm/scale", (E,)) for i in range(L)])
+      m.wi0 = arr([(lp % i + "mlp/wi_0/kernel", (E, F)) for i in range(L)])
+      m.wi1 = arr([(lp % i + "mlp/wi_1/kernel", (E, F)) for i in range(L)])
+      m.wout = arr([(lp % i + "mlp/wo/kernel", (F, E)) for i in range(L)])
+      if cfg.use_post_attn_norm:
+        m.pan = arr([(lp % i + "post_self_attention_norm/scale", (E,)) for i in range(L)])
+      if cfg.use_post_ffw_norm:
+        m.pfn = arr([(lp % i + "post_ffw_norm/scale", (E,)) for i in range(L)])
+      m.block = 2
+      m.attn_cap = float(cfg.attn_logits_soft_cap or 0.0)
+      m.final_cap = float(cfg.final_logits_soft_cap or 0.0) if cfg.logits_via_embedding else 0.0
+      m.window = int(cfg.sliding_window_size or 0)
+      m.norm_logits = 1 if (cfg.logits_via_embedding and cfg.normalize_embedding_logits) else 0
+      m.q_scalar = float(cfg.query_pre_attn_scalar or 0.0)
+      if cfg.local_rope_max_timescale > 0:   # attentions.py:2085-2088
+        self.rope_sin_local, self.rope_cos_local = rope_tables(D, cfg.max_target_length, cfg.rope_min_timescale, cfg.local_rope_max_timescale)
+        m.rope_sin_local, m.rope_cos_local = _p(self.rope_sin_local, _u16p), _p(self.rope_cos_local, _u16p)
     else:
       m.ln1 = arr([(lp % i + "pre_self_attention_layer_norm/scale", (E,)) for i in range(L)])
       m.wq = arr([(lp % i + "self_attention/query/kernel", (E, Q, D)) for i in range(L)])
