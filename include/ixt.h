@@ -57,7 +57,7 @@ typedef struct ixt_config {
    * [local, global] layers; the context then holds 2 x num_decoder_layers (attention, MLP) sub-layers -- sub-layer 2 i is layer i's
    * "local" half, 2 i + 1 its "global" half -- and every `layer` argument of this header (ixt_kv_gather, ixt_op_kv_write,
    * ixt_op_paged_attention) indexes sub-layers.  The fields below are read for gemma2 / gemma3 only and must be zero otherwise. */
-  int32_t decoder_block;           /* base.yml decoder_block: IXT_BLOCK_LLAMA2 | IXT_BLOCK_GEMMA2 | IXT_BLOCK_GEMMA3 */
+  int32_t decoder_block;           /* base.yml decoder_block: IXT_BLOCK_LLAMA2 | IXT_BLOCK_GEMMA2 | IXT_BLOCK_GEMMA3 | IXT_BLOCK_MIXTRAL */
   float attn_logits_soft_cap;      /* attentions.py:1257-1259: score = tanh(score / cap) * cap in f32 before the softmax; 0 = none */
   float final_logits_soft_cap;     /* decoders.py:563-565 (inside the logits_via_embedding branch, as in the reference); 0 = none */
   int32_t sliding_window_size;     /* attentions.py:625-631, local sub-layers: key j visible iff pos - window < j <= pos; 0 = none */
@@ -71,9 +71,16 @@ typedef struct ixt_config {
    * :2246-2248).  Read for gemma3 only: */
   float local_rope_max_timescale;  /* base.yml:603, attentions.py:2085-2088: RoPE base of the local layers; <= 0: rope_max_timescale */
   float query_pre_attn_scalar;     /* gemma3.py:50-58, attentions.py:2262-2264: q = bf16(q * bf16(scalar)) after RoPE; 0 or 1: none */
+  /* IXT_BLOCK_MIXTRAL (layers/mixtral.py:52-170, layers/moe.py:205-1490, configs/models/mixtral-8x7b.yml): the
+   * llama2 wiring with the MLP replaced by a routed mixture -- gate logits (moe.py:170-204), jax.lax.top_k + softmax over the k logits
+   * (:326-345), the selected experts' silu MLPs, sum_k weight_k y_k in f32 (:455-484).  Weights: `MoeBlock_0/gate/kernel` [emb, experts],
+   * `MoeBlock_0/wi_0`, `MoeBlock_0/wi_1` [experts, emb, mlp], `MoeBlock_0/wo` [experts, mlp, emb]; the pre-MoE norm is
+   * `post_self_attention_layer_norm/scale`.  Read for mixtral only (0 or 1 otherwise): */
+  int32_t num_experts;             /* base.yml:160; <= 32 */
+  int32_t num_experts_per_tok;     /* base.yml:161; <= min(num_experts, 8) */
 } ixt_config;
 
-enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2 };
+enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2, IXT_BLOCK_MIXTRAL = 3 };
 
 typedef struct ixt_ctx ixt_ctx;
 

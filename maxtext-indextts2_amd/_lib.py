@@ -34,9 +34,10 @@ class IxtConfig(ctypes.Structure):
       ("sliding_window_size", ctypes.c_int32), ("use_post_attn_norm", ctypes.c_int32), ("use_post_ffw_norm", ctypes.c_int32),
       ("logits_via_embedding", ctypes.c_int32), ("normalize_embedding_logits", ctypes.c_int32),
       ("local_rope_max_timescale", ctypes.c_float), ("query_pre_attn_scalar", ctypes.c_float),
+      ("num_experts", ctypes.c_int32), ("num_experts_per_tok", ctypes.c_int32),
   ]
 
-BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3 = 0, 1, 2
+BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3, BLOCK_MIXTRAL = 0, 1, 2, 3
 
 
 # name -> (restype, argtypes); every symbol include/ixt.h declares

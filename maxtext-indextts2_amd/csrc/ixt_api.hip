@@ -3,6 +3,7 @@
 #include "../../include/ixt.h"
 #include "ixt_kernels.h"
 #include "ixt_gemma_kernels.h"
+#include "ixt_moe_kernels.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -36,9 +37,11 @@ struct LayerW {
   bf16_t *ln1, *wqkv, *wo, *ln2, *wi, *wout;
   bf16_t *pan = nullptr, *pfn = nullptr;   // Gemma-2 / 3: post-attention / post-MLP norm scales
   bf16_t *qn = nullptr, *kn = nullptr;     // Gemma-3: query / key head norm scales [head_dim]
+  bf16_t* gate = nullptr;                  // Mixtral: MoeBlock_0/gate/kernel, row-major [emb][experts]
+  std::vector<bf16_t*> ewi, ewout;         // Mixtral: per expert the (wi_0, wi_1) pair and wo in the dot kernels' layout (wi / wout unused)
 };
 
-enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER, W_PAN = W_PER_LAYER, W_PFN, W_QN, W_KN };
+enum { W_LN1 = 0, W_Q, W_K, W_V, W_O, W_LN2, W_WI0, W_WI1, W_WOUT, W_PER_LAYER, W_PAN = W_PER_LAYER, W_PFN, W_QN, W_KN, W_GATE };
 
 struct TimingPair { hipEvent_t a, b; double bytes; int family; };   // family: 0 canonical dot (incl. unembedding), 1 one-launch decode attention
 
@@ -101,6 +104,11 @@ struct ixt_ctx {
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   // Gemma-2 block (ixt_config.decoder_block == 1): L counts (attention, MLP) sub-layers, two per reference layer (even: local sliding)
   bool gemma = false;
+  bool moe = false;          // Mixtral (decoder_block == 3): the llama2 wiring with a routed mixture of NE expert MLPs, TK per row
+  int NE = 1, TK = 1;
+  int32_t* moe_idx = nullptr;   // [Rmax][TK]
+  float* moe_w = nullptr;       // [Rmax][TK]
+  bf16_t* moe_y = nullptr;      // [Rmax][TK][E]
   bool gemma3 = false;       // Gemma-3 (decoder_block == 2): gemma = true as well; one sub-layer per layer, layer l local unless l % 6 == 5
   float pv_cap = 0.0f;       // soft cap / window of the attention launch being issued (k_attn_pv)
   int pv_window = 0;
@@ -163,7 +171,12 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   const bool gemma = c.decoder_block == IXT_BLOCK_GEMMA2 || gemma3;
   if (c.head_dim != 64 && c.head_dim != 128 && !(c.head_dim == 256 && gemma))
     return set_err(IXT_ERR_UNSUPPORTED, "head_dim %d (64 and 128 built; 256 for decoder_block gemma2 / gemma3)", c.head_dim);
-  if (c.decoder_block != IXT_BLOCK_LLAMA2 && !gemma) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2, gemma2 and gemma3 built)", c.decoder_block);
+  const bool moe = c.decoder_block == IXT_BLOCK_MIXTRAL;
+  if (c.decoder_block != IXT_BLOCK_LLAMA2 && !gemma && !moe) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block %d (llama2, gemma2, gemma3 and mixtral built)", c.decoder_block);
+  if (moe && (c.num_experts < 1 || c.num_experts > IXT_MOE_MAX_EXPERTS || c.num_experts_per_tok < 1 || c.num_experts_per_tok > IXT_MOE_MAX_TOPK ||
+              c.num_experts_per_tok > c.num_experts))
+    return set_err(IXT_ERR_UNSUPPORTED, "mixtral: num_experts in [1, %d], num_experts_per_tok in [1, min(%d, num_experts)]", IXT_MOE_MAX_EXPERTS, IXT_MOE_MAX_TOPK);
+  if (!moe && (c.num_experts > 1 || c.num_experts_per_tok > 1)) return set_err(IXT_ERR_UNSUPPORTED, "num_experts > 1 is built for decoder_block mixtral only");
   if (!gemma3 && (c.local_rope_max_timescale != 0.0f || c.query_pre_attn_scalar != 0.0f))
     return set_err(IXT_ERR_UNSUPPORTED, "local_rope_max_timescale and query_pre_attn_scalar are read for decoder_block gemma3 only");
   if (c.query_pre_attn_scalar < 0.0f) return set_err(IXT_ERR_INVALID, "negative query_pre_attn_scalar");
@@ -193,7 +206,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   ixt_ctx* x = new ixt_ctx();
   x->cfg = c;
   x->E = c.emb_dim; x->Q = c.num_query_heads; x->KV = c.num_kv_heads; x->D = c.head_dim; x->F = c.mlp_dim;
-  x->V = c.vocab_size; x->L = c.num_decoder_layers * ((gemma && !gemma3) ? 2 : 1); x->gemma = gemma; x->gemma3 = gemma3; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
+  x->V = c.vocab_size; x->L = c.num_decoder_layers * ((gemma && !gemma3) ? 2 : 1); x->gemma = gemma; x->gemma3 = gemma3;
+  x->moe = moe; x->NE = moe ? c.num_experts : 1; x->TK = moe ? c.num_experts_per_tok : 1; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
   x->QN = x->Q * x->D; x->KN = x->KV * x->D; x->NQKV = x->QN + 2 * x->KN; x->Tmax = c.max_target_length;
   x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
   x->nsb_max = (x->mpg + IXT_SB - 1) / IXT_SB;
@@ -218,13 +232,25 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     A(dmalloc(x, &w.wqkv, (size_t)E * x->NQKV));
     A(dmalloc(x, &w.wo, (size_t)x->QN * E));
     A(dmalloc(x, &w.ln2, (size_t)E));
-    A(dmalloc(x, &w.wi, (size_t)E * 2 * F));
-    A(dmalloc(x, &w.wout, (size_t)F * E));
+    if (moe) {
+      A(dmalloc(x, &w.gate, (size_t)E * x->NE));
+      w.ewi.assign(x->NE, nullptr); w.ewout.assign(x->NE, nullptr);
+      for (int e = 0; e < x->NE; ++e) { A(dmalloc(x, &w.ewi[e], (size_t)E * 2 * F)); A(dmalloc(x, &w.ewout[e], (size_t)F * E)); }
+      w.wi = w.ewi[0]; w.wout = w.ewout[0];
+    } else {
+      A(dmalloc(x, &w.wi, (size_t)E * 2 * F));
+      A(dmalloc(x, &w.wout, (size_t)F * E));
+    }
     if (gemma && c.use_post_attn_norm) A(dmalloc(x, &w.pan, (size_t)E));
     if (gemma && c.use_post_ffw_norm) A(dmalloc(x, &w.pfn, (size_t)E));
     if (gemma3) { A(dmalloc(x, &w.qn, (size_t)x->D)); A(dmalloc(x, &w.kn, (size_t)x->D)); }
   }
   if (gemma) A(dmalloc(x, &x->glogits, (size_t)x->NLmax * V));
+  if (moe) {
+    A(dmalloc(x, &x->moe_idx, (size_t)R * x->TK));
+    A(dmalloc(x, &x->moe_w, (size_t)R * x->TK));
+    A(dmalloc(x, &x->moe_y, (size_t)R * x->TK * E));
+  }
   // RoPE tables
   host_rope_tables(c, c.rope_max_timescale, x->rope_sin_h, x->rope_cos_h);
   A(dmalloc(x, &x->rope_sin, x->rope_sin_h.size()));
@@ -419,6 +445,25 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
   }
   LayerW& w = c->layers[li];
   uint32_t& m = c->loaded[li];
+  if (c->moe) {   // layers/moe.py:255-312: MoeBlock_0/{gate/kernel [emb, experts], wi_0 / wi_1 [experts, emb, mlp], wo [experts, mlp, emb]}
+    const size_t esz = dtype == IXT_F32 ? 4 : 2;
+    const char* src = (const char*)dev_ptr;
+    if (rest == "MoeBlock_0/gate/kernel") { TRY(expect((int64_t)E * c->NE)); TRY(copy_param(dev_ptr, dtype, w.gate, E, c->NE, c->NE, st)); m |= 1u << W_GATE; return IXT_OK; }
+    if (rest == "MoeBlock_0/wi_0" || rest == "MoeBlock_0/wi_1") {
+      const int which = rest == "MoeBlock_0/wi_1" ? 1 : 0;
+      TRY(expect((int64_t)c->NE * E * F));
+      for (int e = 0; e < c->NE; ++e) TRY(tile_param(src + (size_t)e * E * F * esz, dtype, w.ewi[e], E, F, which, st, 2));
+      m |= 1u << (which ? W_WI1 : W_WI0);
+      return IXT_OK;
+    }
+    if (rest == "MoeBlock_0/wo") {
+      TRY(expect((int64_t)c->NE * F * E));
+      for (int e = 0; e < c->NE; ++e) TRY(tile_param(src + (size_t)e * F * E * esz, dtype, w.ewout[e], F, E, 0, st));
+      m |= 1u << W_WOUT;
+      return IXT_OK;
+    }
+    if (rest.rfind("mlp/", 0) == 0) return set_err(IXT_ERR_INVALID, "unknown parameter path %s (decoder_block mixtral has MoeBlock_0, no mlp)", path);
+  }
   if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
   else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st, 1, c->D)); m |= 1u << W_Q; }
   else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st, 1, c->D)); m |= 1u << W_K; }
@@ -439,6 +484,7 @@ extern "C" int ixt_weights_complete(ixt_ctx* c) {
     if (c->layers[i].pan) want |= 1u << W_PAN;
     if (c->layers[i].pfn) want |= 1u << W_PFN;
     if (c->layers[i].qn) want |= (1u << W_QN) | (1u << W_KN);
+    if (c->layers[i].gate) want |= 1u << W_GATE;
     if (c->loaded[i] != want) return 0;
   }
   return c->loaded[c->L] == 7 ? 1 : 0;
@@ -1134,7 +1180,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
   const bool final_fused = nl == R && lrow0 == 0 && lrows == nullptr;   // decode: every row is unembedded
-  const bool ring = R >= c->ring_min_rows;
+  const bool ring = R >= c->ring_min_rows && !c->moe;   // Mixtral: the split-K dots (every expert is a launch sequence of its own)
   const int fused_min = c->attn_fused_min_blocks;
   const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
   const bool attn_one_launch = R * c->KV >= fused_min && fused_lds <= 64 * 1024;
@@ -1212,6 +1258,32 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     }
     TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
     TRY(launch_rownorm(c, 1, R, nullptr, &dr, hcur, hnext, w.ln2, c->xn, st));
+    if (c->moe) {
+      // mixtral.py:123-160 / moe.py:855-942.  Every expert runs over ALL rows and only the rows that selected it keep the result: a row's
+      // output does not depend on which other rows share its launch, so this equals the routed (permute / gmm / unpermute) form bit for
+      // bit; it reads each expert's kernels once per pass, which is what decode with >= ~16 rows needs anyway, and spends
+      // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
+      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
+      LAUNCHCHK();
+      for (int e = 0; e < c->NE; ++e) {
+        TRY(launch_dot(c, c->xn, w.ewi[e], E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
+        hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
+        LAUNCHCHK();
+        TRY(launch_dot(c, c->hact, w.ewout[e], F, E, R, c->part, c->part_floats, false, st, &dr));
+        hipLaunchKernelGGL(k_moe_scatter, dim3((E + 255) / 256, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, E, e, c->TK, c->moe_idx, c->moe_y);
+        LAUNCHCHK();
+      }
+      hipLaunchKernelGGL(k_moe_combine, dim3((E + 255) / 256, R), dim3(256), 0, st, c->moe_y, c->moe_w, E, c->TK, c->part);
+      LAUNCHCHK();
+      dr.slices = 1; dr.slice_stride = (size_t)R * E;
+      if (next_scale != nullptr) {
+        TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st));
+      } else {
+        hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
+        LAUNCHCHK();
+      }
+      continue;
+    }
     TRY(launch_dot(c, c->xn, w.wi, E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
     hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
     LAUNCHCHK();

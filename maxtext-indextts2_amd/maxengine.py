@@ -110,7 +110,10 @@ class MaxEngine(engine_api.Engine):
       c.logits_via_embedding = 1 if config.logits_via_embedding else 0
       c.normalize_embedding_logits = 1 if config.normalize_embedding_logits else 0
     elif tuple(config.mlp_activations) != ("silu", "linear"):
-      raise ValueError("decoder_block llama2 is built with mlp_activations ['silu', 'linear']")
+      raise ValueError(f"decoder_block {config.decoder_block} is built with mlp_activations ['silu', 'linear']")
+    elif config.decoder_block == "mixtral":            # layers/mixtral.py:52-170, layers/moe.py
+      c.decoder_block = _lib.BLOCK_MIXTRAL
+      c.num_experts, c.num_experts_per_tok = int(config.num_experts), int(config.num_experts_per_tok)
     self._staging = int(config.ixt_staging_groups)
     self._packed_rows = max(int(config.ixt_max_packed_rows), int(config.max_prefill_predict_length))
     self._ccfg = c

@@ -140,8 +140,13 @@ def _derive(keys: Dict[str, Any]) -> None:
     keys["pagedattn_max_pages_per_group"] = -(-keys["max_target_length"] // keys["pagedattn_tokens_per_page"])
   if keys["attention"] not in VALID_ATTENTION:
     raise ValueError(f"Invalid attention {keys['attention']}; valid: {VALID_ATTENTION}")
-  if keys["decoder_block"] not in ("llama2", "default", "gemma2", "gemma3"):
-    raise ValueError(f"decoder_block {keys['decoder_block']} is outside this build's hot path (llama2, gemma2 and gemma3 are built)")
+  if keys["decoder_block"] not in ("llama2", "default", "gemma2", "gemma3", "mixtral"):
+    raise ValueError(f"decoder_block {keys['decoder_block']} is outside this build's hot path (llama2, gemma2, gemma3 and mixtral are built)")
+  if keys["decoder_block"] == "mixtral":
+    if not 1 <= keys["num_experts_per_tok"] <= min(keys["num_experts"], 8) or keys["num_experts"] > 32:
+      raise ValueError("mixtral: 1 <= num_experts_per_tok <= min(num_experts, 8) and num_experts <= 32")
+  elif keys["num_experts"] != 1 or keys["num_experts_per_tok"] != 1:
+    raise ValueError("num_experts > 1 is built for decoder_block mixtral only")
   if keys["decoder_block"] not in ("gemma2", "gemma3") and (keys["attn_logits_soft_cap"] or keys["final_logits_soft_cap"] or keys["sliding_window_size"] or
                                             keys["use_post_attn_norm"] or keys["use_post_ffw_norm"] or keys["logits_via_embedding"]):
     raise ValueError("soft caps, sliding_window_size, post norms and logits_via_embedding are built for decoder_block gemma2 / gemma3 only")

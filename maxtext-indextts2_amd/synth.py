@@ -157,8 +157,36 @@ def synth_weights_gemma3(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
   return w
 
 
+def synth_weights_mixtral(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
+  """Random Mixtral tree (layers/mixtral.py:52-170; MoeBlock_0: gate/kernel [emb, experts], wi_0 / wi_1 [experts, emb, mlp], wo [experts, mlp, emb]).
+  The gate kernel is drawn 4 x wider than a dense kernel so that the routing logits are well separated and vary from row to row."""
+  rng = np.random.Generator(np.random.PCG64(seed))
+  E, Q, KV, D, F, V, L, NE = (cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size,
+                              cfg.num_decoder_layers, cfg.num_experts)
+  one = f32_to_bf16_bits(np.ones((E,), np.float32))
+  w: Dict[str, np.ndarray] = {}
+  w["params/token_embedder/embedding"] = f32_to_bf16_bits(rng.standard_normal(V * E, dtype=np.float32)).reshape(V, E)
+  for i in range(L):
+    p = f"params/decoder/layers_{i}/"
+    w[p + "pre_self_attention_layer_norm/scale"] = one.copy()
+    w[p + "self_attention/query/kernel"] = _dense(rng, (E, Q, D), E, math.sqrt(D))
+    w[p + "self_attention/key/kernel"] = _dense(rng, (E, KV, D), E)
+    w[p + "self_attention/value/kernel"] = _dense(rng, (E, KV, D), E)
+    w[p + "self_attention/out/kernel"] = _dense(rng, (Q, D, E), Q * D)
+    w[p + "post_self_attention_layer_norm/scale"] = one.copy()
+    w[p + "MoeBlock_0/gate/kernel"] = _dense(rng, (E, NE), E, 0.25)
+    w[p + "MoeBlock_0/wi_0"] = _dense(rng, (NE, E, F), E)
+    w[p + "MoeBlock_0/wi_1"] = _dense(rng, (NE, E, F), E)
+    w[p + "MoeBlock_0/wo"] = _dense(rng, (NE, F, E), F)
+  w["params/decoder/decoder_norm/scale"] = one.copy()
+  w["params/decoder/logits_dense/kernel"] = _dense(rng, (E, V), E)
+  return w
+
+
 def synth_weights(cfg, seed: int = 0) -> Dict[str, np.ndarray]:
   """cfg needs vocab_size, emb_dim, num_query_heads, num_kv_heads, head_dim, mlp_dim, num_decoder_layers."""
+  if getattr(cfg, "decoder_block", "llama2") == "mixtral":
+    return synth_weights_mixtral(cfg, seed)
   if getattr(cfg, "decoder_block", "llama2") == "gemma2":
     return synth_weights_gemma2(cfg, seed)
   if getattr(cfg, "decoder_block", "llama2") == "gemma3":

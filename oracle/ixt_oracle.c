@@ -63,7 +63,7 @@ typedef struct orc_model {
   uint16_t* vpages;
   /* SURVEY.md section 8(f) item 3, Gemma-2 block (layers/gemma2.py:69-236): nlayers then counts (attention, MLP) sub-layers, two per
    * reference layer: even = local sliding window, odd = global.  All zero / NULL: the llama2 block. */
-  int32_t block;                      /* 0 llama2, 1 gemma2, 2 gemma3 */
+  int32_t block;                      /* 0 llama2, 1 gemma2, 2 gemma3, 3 mixtral */
   float attn_cap;                     /* attn_logits_soft_cap (attentions.py:1257-1259), 0: none */
   float final_cap;                    /* final_logits_soft_cap (decoders.py:563-565), 0: none */
   int32_t window;                     /* sliding_window_size of the local sub-layers (attentions.py:625-631), 0: none */
@@ -77,6 +77,11 @@ typedef struct orc_model {
   float q_scalar;                     /* query_pre_attn_scalar (gemma3.py:50-58, attentions.py:2262-2264): q * scalar after RoPE; 0 or 1: none */
   const uint16_t* rope_sin_local;     /* [max_pos][hd/2]: tables of the local layers (local_rope_max_timescale, attentions.py:2085-2088); NULL: rope_sin */
   const uint16_t* rope_cos_local;
+  /* Mixtral block (block == 3; layers/mixtral.py:52-170, layers/moe.py:170-204, :326-345, :420-484, :855-942):
+   * the llama2 wiring with the MLP replaced by a routed mixture: gate logits -> top_k experts -> softmax over the k logits ->
+   * sum_k weight_k * MLP_{expert_k}(x).  ln2 is post_self_attention_layer_norm; wi0 / wi1 / wout hold all experts of a layer. */
+  int32_t n_exp, top_k;               /* num_experts, num_experts_per_tok (<= 8) */
+  const uint16_t* const* gate;        /* [L] -> [emb][n_exp]  MoeBlock_0/gate/kernel; wi0/wi1: [L] -> [n_exp][emb][mlp]; wout: [L] -> [n_exp][mlp][emb] */
 } orc_model;
 
 /* ---------------------------------------------------------------- scalars */
@@ -586,6 +591,97 @@ float orc_logit_post(float v, int normalize, int emb, float cap) {
 }
 
 /* ---------------------------------------------------------------- forward */
+/* ---------------------------------------------------------------- routed mixture of experts (block == 3) */
+/* Gate logit of one row for expert e (GateLogit, moe.py:170-204: a DenseGeneral to num_experts columns, bf16 in / bf16 out).  The column
+ * count (8) is below a matrix-core tile, so the canonical order of this dot is the vector one of the RMSNorm statistics: chunks of 8
+ * consecutive k as fma chains from +0, 64 chunks by xor-butterfly (missing chunks = +0), blocks added in order; bf16 result. */
+float orc_gate_logit(const uint16_t* x, const uint16_t* gate, int E, int n_exp, int e) {
+  int nch = E / 8, nblk = (nch + 63) / 64;
+  float total = 0.0f;
+  for (int b = 0; b < nblk; ++b) {
+    float v[64];
+    for (int l = 0; l < 64; ++l) {
+      int ch = b * 64 + l;
+      float a = 0.0f;
+      if (ch < nch)
+        for (int j = 0; j < 8; ++j) a = fmaf(bf2f(x[ch * 8 + j]), bf2f(gate[(size_t)(ch * 8 + j) * n_exp + e]), a);
+      v[l] = a;
+    }
+    for (int off = 1; off < 64; off <<= 1) {
+      float t[64];
+      for (int l = 0; l < 64; ++l) t[l] = v[l] + v[l ^ off];
+      memcpy(v, t, sizeof(v));
+    }
+    total = total + v[0];
+  }
+  return rbf(total);
+}
+
+/* moe.py:326-345: jax.lax.top_k over the bf16 logits (descending, equal values: lower index first), then softmax over the k values in
+ * f32 -- m = the largest, e_j = orc_exp(v_j - m), s = e_0 + e_1 + ... in order, weight_j = bf16(e_j / s). */
+void orc_route_row(const float* logits, int n_exp, int top_k, int32_t* idx, float* weight) {
+  float v[8], ex[8];
+  uint32_t taken = 0;
+  for (int j = 0; j < top_k; ++j) {
+    int best = -1;
+    for (int e = 0; e < n_exp; ++e)
+      if (!((taken >> e) & 1u) && (best < 0 || logits[e] > logits[best])) best = e;
+    taken |= 1u << best;
+    idx[j] = best;
+    v[j] = logits[best];
+  }
+  float s = 0.0f;
+  for (int j = 0; j < top_k; ++j) { ex[j] = orc_exp(v[j] - v[0]); s = s + ex[j]; }
+  for (int j = 0; j < top_k; ++j) weight[j] = rbf(ex[j] / s);
+}
+
+/* xn bf16 [R][emb] (post_self_attention_layer_norm output) -> out bf16 [R][emb] = the mixture output (moe.py:855-942 + unpermute :455-484:
+ * per selected expert the MlpBlock arithmetic (bf16 dots, silu gate), then t = 0; t = fma(y_j, weight_j, t) for j = 0 .. k-1 in top_k
+ * order (the f32 einsum "BKE,BK -> BE"), bf16(t)).  routing_out (may be NULL): int32 [R][top_k] expert ids. */
+void orc_moe_rows(const orc_model* m, int L, const uint16_t* xn, int R, uint16_t* out, int32_t* routing_out) {
+  int E = m->emb, F = m->mlp, NE = m->n_exp, K = m->top_k;
+  int32_t* idx = (int32_t*)malloc(sizeof(int32_t) * (size_t)R * K);
+  float* wgt = (float*)malloc(sizeof(float) * (size_t)R * K);
+  uint16_t* ybuf = (uint16_t*)calloc((size_t)R * K * E, sizeof(uint16_t));
+  uint16_t* xg = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * E);
+  uint16_t* a = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * F);
+  uint16_t* b = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * F);
+  uint16_t* y = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)R * E);
+  int32_t* rows = (int32_t*)malloc(sizeof(int32_t) * (size_t)R);
+  int32_t* slot = (int32_t*)malloc(sizeof(int32_t) * (size_t)R);
+  float* scratch = (float*)malloc(sizeof(float) * (size_t)R * (F > E ? F : E));
+  for (int r = 0; r < R; ++r) {
+    float gl[32];
+    for (int e = 0; e < NE; ++e) gl[e] = orc_gate_logit(xn + (size_t)r * E, m->gate[L], E, NE, e);
+    orc_route_row(gl, NE, K, idx + (size_t)r * K, wgt + (size_t)r * K);
+  }
+  for (int e = 0; e < NE; ++e) {
+    int n = 0;
+    for (int r = 0; r < R; ++r)
+      for (int j = 0; j < K; ++j)
+        if (idx[(size_t)r * K + j] == e) { rows[n] = r; slot[n] = j; memcpy(xg + (size_t)n * E, xn + (size_t)r * E, sizeof(uint16_t) * E); ++n; }
+    if (n == 0) continue;
+    dot_rows_bf16(xg, E, n, m->wi0[L] + (size_t)e * E * F, E, F, a, F, scratch);
+    dot_rows_bf16(xg, E, n, m->wi1[L] + (size_t)e * E * F, E, F, b, F, scratch);
+    for (size_t i = 0; i < (size_t)n * F; ++i) {
+      float av = bf2f(a[i]);
+      float sg = rbf(1.0f / (1.0f + orc_exp(-av)));
+      float u = rbf(av * sg);
+      a[i] = f2bf(u * bf2f(b[i]));
+    }
+    dot_rows_bf16(a, F, n, m->wout[L] + (size_t)e * F * E, F, E, y, E, scratch);
+    for (int i = 0; i < n; ++i) memcpy(ybuf + ((size_t)rows[i] * K + slot[i]) * E, y + (size_t)i * E, sizeof(uint16_t) * E);
+  }
+  for (int r = 0; r < R; ++r)
+    for (int c = 0; c < E; ++c) {
+      float t = 0.0f;
+      for (int j = 0; j < K; ++j) t = fmaf(bf2f(ybuf[((size_t)r * K + j) * E + c]), wgt[(size_t)r * K + j], t);
+      out[(size_t)r * E + c] = f2bf(t);
+    }
+  if (routing_out) memcpy(routing_out, idx, sizeof(int32_t) * (size_t)R * K);
+  free(idx); free(wgt); free(ybuf); free(xg); free(a); free(b); free(y); free(rows); free(slot); free(scratch);
+}
+
 /* R rows processed as one ragged batch (a prefill chunk of one slot, or one decode
  * token for each of several slots).  Per layer ALL rows' K/V are written to their
  * pages first, then each row attends to positions [0, pos[r]] of its slot
@@ -618,7 +714,7 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
   int max_len = 0;
   for (int r = 0; r < R; ++r)
     if (pos[r] + 1 > max_len) max_len = pos[r] + 1;
-  const int gemma = m->block >= 1;
+  const int gemma = m->block == 1 || m->block == 2;
 
   for (int r = 0; r < R; ++r) memcpy(h + (size_t)r * E, m->embedding + (size_t)tokens[r] * E, sizeof(uint16_t) * E);
 
@@ -668,6 +764,11 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
       for (int r = 0; r < R; ++r) orc_rmsnorm(t0 + (size_t)r * E, m->pan[L], t0 + (size_t)r * E, E, m->eps);
     for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
     for (int r = 0; r < R; ++r) orc_rmsnorm(h + (size_t)r * E, m->ln2[L], xn + (size_t)r * E, E, m->eps);
+    if (m->block == 3) {   /* mixtral.py:123-160: the routed mixture takes the MLP's place */
+      orc_moe_rows(m, L, xn, R, t0, NULL);
+      for (size_t i = 0; i < (size_t)R * E; ++i) h[i] = f2bf(bf2f(h[i]) + bf2f(t0[i]));
+      continue;
+    }
     dot_rows_bf16(xn, E, R, m->wi0[L], E, F, t0, F, scratch);
     dot_rows_bf16(xn, E, R, m->wi1[L], E, F, t1, F, scratch);
     for (size_t i = 0; i < (size_t)R * F; ++i) {

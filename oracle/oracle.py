@@ -56,6 +56,7 @@ class _CModel(ctypes.Structure):
       ("block", ctypes.c_int32), ("attn_cap", ctypes.c_float), ("final_cap", ctypes.c_float), ("window", ctypes.c_int32),
       ("norm_logits", ctypes.c_int32), ("pan", _u16pp), ("pfn", _u16pp),
       ("qn", _u16pp), ("kn", _u16pp), ("q_scalar", ctypes.c_float), ("rope_sin_local", _u16p), ("rope_cos_local", _u16p),
+      ("n_exp", ctypes.c_int32), ("top_k", ctypes.c_int32), ("gate", _u16pp),
   ]
 
 
@@ -356,6 +357,10 @@ class OracleConfig:
   # i % 6 == 5; query / key RMSNorm over head_dim; q * query_pre_attn_scalar after RoPE; the local layers' own RoPE base
   local_rope_max_timescale: float = -1.0
   query_pre_attn_scalar: float = 0.0
+  # Mixtral block (layers/mixtral.py:52-170, layers/moe.py; configs/models/mixtral-8x7b.yml): the llama2 wiring with a routed mixture of
+  # num_experts MLPs, num_experts_per_tok of them per token
+  num_experts: int = 1
+  num_experts_per_tok: int = 1
 
   @property
   def sublayers(self) -> int:
@@ -433,6 +438,19 @@ class OracleModel:
       m.final_cap = float(cfg.final_logits_soft_cap or 0.0) if cfg.logits_via_embedding else 0.0   # decoders.py:552-565: inside the tied branch
       m.window = int(cfg.sliding_window_size or 0)
       m.norm_logits = 1 if (cfg.logits_via_embedding and cfg.normalize_embedding_logits) else 0
+    elif cfg.decoder_block == "mixtral":
+      NE = cfg.num_experts
+      m.ln1 = arr([(lp % i + "pre_self_attention_layer_norm/scale", (E,)) for i in range(L)])
+      m.wq = arr([(lp % i + "self_attention/query/kernel", (E, Q, D)) for i in range(L)])
+      m.wk = arr([(lp % i + "self_attention/key/kernel", (E, KV, D)) for i in range(L)])
+      m.wv = arr([(lp % i + "self_attention/value/kernel", (E, KV, D)) for i in range(L)])
+      m.wo = arr([(lp % i + "self_attention/out/kernel", (Q, D, E)) for i in range(L)])
+      m.ln2 = arr([(lp % i + "post_self_attention_layer_norm/scale", (E,)) for i in range(L)])   # mixtral.py:123-130
+      m.gate = arr([(lp % i + "MoeBlock_0/gate/kernel", (E, NE)) for i in range(L)])
+      m.wi0 = arr([(lp % i + "MoeBlock_0/wi_0", (NE, E, F)) for i in range(L)])
+      m.wi1 = arr([(lp % i + "MoeBlock_0/wi_1", (NE, E, F)) for i in range(L)])
+      m.wout = arr([(lp % i + "MoeBlock_0/wo", (NE, F, E)) for i in range(L)])
+      m.block, m.n_exp, m.top_k = 3, NE, cfg.num_experts_per_tok
     elif gemma3:
       # layers/gemma3.py:83-200 parameter names (the MLP pre-norm lives inside mlp_block: use_pre_norm=True)
       m.ln1 = arr([(lp % i + "pre_self_attention_norm/scale", (E,)) for i in range(L)])

@@ -34,7 +34,8 @@ def oracle_config(cfg):
       rope_max_timescale=float(cfg.rope_max_timescale), max_target_length=cfg.max_target_length,
       max_prefill_predict_length=cfg.max_prefill_predict_length, pagedattn_num_pages=cfg.pagedattn_num_pages,
       pagedattn_tokens_per_page=cfg.pagedattn_tokens_per_page, pagedattn_max_pages_per_group=cfg.pagedattn_max_pages_per_group,
-      max_slots=int(cfg.per_device_batch_size), decoder_block=cfg.decoder_block if cfg.decoder_block in ("gemma2", "gemma3") else "llama2",
+      max_slots=int(cfg.per_device_batch_size), decoder_block=cfg.decoder_block if cfg.decoder_block in ("gemma2", "gemma3", "mixtral") else "llama2",
+      num_experts=int(cfg.num_experts), num_experts_per_tok=int(cfg.num_experts_per_tok),
       attn_logits_soft_cap=float(cfg.attn_logits_soft_cap or 0.0), final_logits_soft_cap=float(cfg.final_logits_soft_cap or 0.0),
       sliding_window_size=int(cfg.sliding_window_size or 0), use_post_attn_norm=bool(cfg.use_post_attn_norm),
       use_post_ffw_norm=bool(cfg.use_post_ffw_norm), logits_via_embedding=bool(cfg.logits_via_embedding),

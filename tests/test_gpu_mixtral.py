@@ -1,0 +1,71 @@
+"""GPU parity of the Mixtral block (layers/mixtral.py:52-170, layers/moe.py) against the oracle through the
+engine's call order: tokens, f32 logits bits, K and V of every layer, PageState.  8 experts, 2 per token, 4 query heads per kv head."""
+import numpy as np
+import pytest
+
+import helpers as H
+from test_gpu_engine import packed_prefill_pair, run_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def _cfg(**kw):
+  base = dict(max_prefill_predict_length=48, max_target_length=128)
+  base.update(kw)
+  return H.make_config("mixtral-tiny", **base)
+
+
+def _prompt(vocab, n, seed):
+  return np.random.Generator(np.random.PCG64(seed)).integers(1, vocab, size=n).astype(np.int32)
+
+
+def test_mixtral_single_slot():
+  cfg = _cfg()
+  w = H.synth.synth_weights(cfg, 0)
+  run_pair(cfg, w, [(_prompt(cfg.vocab_size, 48, 1234), 41)], steps=40)
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_mixtral_batched_ragged(use_graph):
+  cfg = _cfg(per_device_batch_size=6.0, pagedattn_num_pages=160, ixt_use_hip_graph=use_graph)
+  w = H.synth.synth_weights(cfg, 1)
+  prompts = [(_prompt(cfg.vocab_size, 48, 100 + s), [48, 1, 25, 24, 33][s]) for s in range(5)]
+  run_pair(cfg, w, prompts, steps=36)
+
+
+def test_mixtral_chunked_prefill():
+  cfg = _cfg(max_prefill_predict_length=16, per_device_batch_size=2.0, use_chunked_prefill=True, prefill_chunk_size=16)
+  w = H.synth.synth_weights(cfg, 2)
+  run_pair(cfg, w, [(_prompt(cfg.vocab_size, 48, 77), 44), (_prompt(cfg.vocab_size, 48, 78), 30)], steps=12, chunks=[[16, 16, 12], [16, 14]])
+
+
+@pytest.mark.parametrize("ne,k", [(4, 1), (8, 8), (16, 4), (1, 1)])
+def test_mixtral_expert_counts(ne, k):
+  cfg = _cfg(per_device_batch_size=2.0, num_experts=ne, num_experts_per_tok=k)
+  w = H.synth.synth_weights(cfg, 4)
+  prompts = [(_prompt(cfg.vocab_size, 48, 50 + s), [37, 29][s]) for s in range(2)]
+  run_pair(cfg, w, prompts, steps=10)
+
+
+def test_mixtral_many_rows():
+  """130 decode slots and a 150-row prefill: the per-expert dots take their >= 128-row forms."""
+  cfg = H.make_config("mixtral-tiny", max_prefill_predict_length=160, max_target_length=192, per_device_batch_size=130.0, pagedattn_num_pages=130 * 24 + 8,
+                      base_num_decoder_layers=2)
+  w = H.synth.synth_weights(cfg, 6)
+  prompts = [(_prompt(cfg.vocab_size, 160, 900 + s), 150 if s == 0 else [9, 17, 33, 2][s % 4]) for s in range(130)]
+  run_pair(cfg, w, prompts, steps=3, check_logits=False)
+
+
+@pytest.mark.parametrize("nprompts,hi", [(6, 32), (24, 12)])
+def test_mixtral_packed_prefill(nprompts, hi):
+  packed_prefill_pair(nprompts, hi, model_name="mixtral-tiny")
+
+
+def test_mixtral_8x7b_widths():
+  """The widths of configs/models/mixtral-8x7b.yml (emb 4096, 32 x 128 query heads over 8 kv heads, mlp 14336, 8 experts, 2 per token) with 1 of
+  its 32 layers and a 2048-row vocabulary: every projection and expert kernel shape against the oracle."""
+  cfg = H.make_config("mixtral-8x7b", base_num_decoder_layers=1, vocab_size=2048, max_prefill_predict_length=16, max_target_length=32,
+                      per_device_batch_size=2.0, pagedattn_num_pages=16)
+  w = H.synth.synth_weights(cfg, 10)
+  prompts = [(_prompt(cfg.vocab_size, 16, 80 + s), [13, 6][s]) for s in range(2)]
+  run_pair(cfg, w, prompts, steps=3)
