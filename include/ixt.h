@@ -181,6 +181,15 @@ int ixt_op_dot(ixt_ctx* ctx, const uint16_t* x, const uint16_t* w, float* out, i
 int ixt_op_rmsnorm(ixt_ctx* ctx, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream);
 /* RotaryEmbedding.__call__ (embeddings.py:277-315) in place on x bf16[R][nheads][head_dim], positions int32[R]. */
 int ixt_op_rope(ixt_ctx* ctx, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream);
+/* The Mixtral block piece by piece (decoder_block mixtral, weights of `layer` loaded), for a caller that places an exchange between the
+ * pieces (expert parallelism, layers/moe.py:785-938): x bf16 [R][emb] row-major (the post_self_attention_layer_norm output).
+ *   route   (moe.py:170-204, :326-345): experts_out int32 [R][num_experts_per_tok] in top_k order, weights_out f32 [R][k] (bf16 values);
+ *   expert  (moe.py:862-874): out bf16 [R][emb] = wo_e(bf16(bf16(silu(wi_0_e x)) * wi_1_e x)) of one expert over all R rows (R <= the ctx's
+ *           row capacity);
+ *   combine (moe.py:455-484): y bf16 [R][k][emb] -> out bf16 [R][emb] = bf16(fma chain over j of y[r][j] * weights[r][j]). */
+int ixt_op_moe_route(ixt_ctx* ctx, int layer, const uint16_t* x, int R, int32_t* experts_out, float* weights_out, void* stream);
+int ixt_op_moe_expert(ixt_ctx* ctx, int layer, int expert, const uint16_t* x, int R, uint16_t* out, void* stream);
+int ixt_op_moe_combine(ixt_ctx* ctx, const uint16_t* y, const float* weights, int R, uint16_t* out, void* stream);
 /* MlpBlock gate (linears.py:459-464): out = bf16(bf16(silu(a)) * b), n elements. */
 int ixt_op_swiglu(ixt_ctx* ctx, const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n, void* stream);
 /* The Gemma gate (mlp_activations ["gelu", "linear"], linears.py:449-464 with jax.nn.gelu approximate=True on bf16 values, every primitive

@@ -68,6 +68,9 @@ SIGNATURES = {
     "ixt_op_dot": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_rmsnorm": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_op_rope": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_op_moe_route": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]),
+    "ixt_op_moe_expert": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
+    "ixt_op_moe_combine": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, vp, vp]),
     "ixt_op_swiglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_geglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_residual": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),

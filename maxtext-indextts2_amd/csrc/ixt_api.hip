@@ -1441,6 +1441,53 @@ extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, floa
   return IXT_OK;
 }
 
+// ---- Mixtral block piece by piece (layers/moe.py): what an expert-parallel caller (moe_ep.py) runs on each side of its exchange
+static int check_moe_layer(ixt_ctx* c, int layer) {
+  if (!c) return set_err(IXT_ERR_INVALID, "null ctx");
+  if (!c->moe) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block is not mixtral");
+  if (layer < 0 || layer >= c->L) return set_err(IXT_ERR_RANGE, "layer %d out of range [0, %d)", layer, c->L);
+  const uint32_t need = (1u << W_GATE) | (1u << W_WI0) | (1u << W_WI1) | (1u << W_WOUT);
+  if ((c->loaded[layer] & need) != need) return set_err(IXT_ERR_NOT_LOADED, "MoeBlock_0 of layer %d is not loaded", layer);
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_moe_route(ixt_ctx* c, int layer, const uint16_t* x, int R, int32_t* experts_out, float* weights_out, void* stream) {
+  TRY(check_moe_layer(c, layer));
+  if (!x || !experts_out || !weights_out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  TRY(transpose_rows(c, x, R, c->E, st));
+  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_moe_expert(ixt_ctx* c, int layer, int expert, const uint16_t* x, int R, uint16_t* out, void* stream) {
+  TRY(check_moe_layer(c, layer));
+  if (!x || !out || R <= 0 || R > c->Rmax) return set_err(IXT_ERR_INVALID, "bad argument (rows in (0, %d])", c->Rmax);
+  if (expert < 0 || expert >= c->NE) return set_err(IXT_ERR_RANGE, "expert %d out of range [0, %d)", expert, c->NE);
+  hipStream_t st = (hipStream_t)stream;
+  const int E = c->E, F = c->F;
+  const LayerW& w = c->layers[layer];
+  DotResult dr;
+  TRY(transpose_rows(c, x, R, E, st));
+  TRY(launch_dot(c, c->xt_op, w.ewi[expert], E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
+  hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
+  LAUNCHCHK();
+  TRY(launch_dot(c, c->hact, w.ewout[expert], F, E, R, c->part, c->part_floats, false, st, &dr));
+  const size_t n = (size_t)R * E;
+  hipLaunchKernelGGL(k_slices_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, n, out);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_moe_combine(ixt_ctx* c, const uint16_t* y, const float* weights, int R, uint16_t* out, void* stream) {
+  if (!c || !c->moe) return set_err(IXT_ERR_UNSUPPORTED, "decoder_block is not mixtral");
+  if (!y || !weights || !out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_moe_combine, dim3((c->E + 255) / 256, R), dim3(256), 0, (hipStream_t)stream, y, weights, c->E, c->TK, (float*)nullptr, out);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
 extern "C" int ixt_op_rmsnorm(ixt_ctx* c, const uint16_t* x, const uint16_t* scale, uint16_t* out, int R, int E, void* stream) {
   if (!c || !x || !scale || !out || R <= 0 || E % 8) return set_err(IXT_ERR_INVALID, "bad argument");
   RowNormArgs a{};

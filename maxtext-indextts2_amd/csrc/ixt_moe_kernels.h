@@ -62,10 +62,18 @@ __global__ __launch_bounds__(256) void k_moe_scatter(const float* part, int slic
 }
 
 // out[r][c] = bf16(fma chain over j of y_j * weight_j) as one f32 "slice" (the residual / norm kernels take it from there).
-__global__ __launch_bounds__(256) void k_moe_combine(const bf16_t* ybuf, const float* w, int E, int top_k, float* out /*[R][E]*/) {
+__global__ __launch_bounds__(256) void k_moe_combine(const bf16_t* ybuf, const float* w, int E, int top_k, float* out /*[R][E]*/, bf16_t* out16 = nullptr) {
   const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
   if (c >= E) return;
   float t = 0.0f;
   for (int j = 0; j < top_k; ++j) t = __builtin_fmaf(bf2f(ybuf[((size_t)r * top_k + j) * E + c]), w[(size_t)r * top_k + j], t);
-  out[(size_t)r * E + c] = rbf(t);
+  if (out != nullptr) out[(size_t)r * E + c] = rbf(t);
+  if (out16 != nullptr) out16[(size_t)r * E + c] = f2bf(t);
+}
+
+// bf16(sum of slices) of a [R][N] projection (op-level entry points)
+__global__ __launch_bounds__(256) void k_slices_to_bf16(const float* part, int slices, size_t slice_stride, size_t n, bf16_t* out) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  out[i] = f2bf(sum_slices<16>(part + i, slice_stride, slices));
 }

@@ -51,10 +51,11 @@ def permute(selected_experts: torch.Tensor, num_experts: int) -> Tuple[torch.Ten
 
 
 def expert_parallel_apply(x: torch.Tensor, selected_experts: torch.Tensor, num_experts: int,
-                          expert_fn: Callable[[int, torch.Tensor], torch.Tensor], group=None) -> torch.Tensor:
+                          expert_fn: Callable[[int, torch.Tensor], torch.Tensor], group=None, always_exchange: bool = False) -> torch.Tensor:
   """x [rows, emb] and selected_experts int [rows, k] of THIS rank -> y [rows, k, emb] with y[r, j] = expert_fn(selected_experts[r, j], x[r]),
   every expert evaluated on the rank that owns it (experts_per_rank = num_experts / world consecutive ids per rank).  expert_fn(e, rows)
-  is called once per local expert that received rows, with the global expert id."""
+  is called once per local expert that received rows, with the global expert id.  always_exchange: run the collectives on a one-rank
+  group too (exercises the RCCL calls on a one-GPU box)."""
   world = dist.get_world_size(group) if dist.is_initialized() else 1
   rank = dist.get_rank(group) if dist.is_initialized() else 0
   if num_experts % world:
@@ -64,7 +65,8 @@ def expert_parallel_apply(x: torch.Tensor, selected_experts: torch.Tensor, num_e
   order, src_rows, group_size = permute(selected_experts, num_experts)
   sorted_x = x.index_select(0, src_rows)                               # copies grouped by expert = grouped by owning rank
   send_counts = group_size.reshape(world, per_rank)                    # [dest rank][its local expert]
-  if world == 1:
+  exchange = world > 1 or (always_exchange and dist.is_initialized())
+  if not exchange:
     recv_counts = send_counts.clone()
     recv_x = sorted_x
   else:
@@ -91,7 +93,7 @@ def expert_parallel_apply(x: torch.Tensor, selected_experts: torch.Tensor, num_e
       continue
     idx = torch.cat([torch.arange(a, a + n, device=x.device) for a, n in pieces])
     recv_y.index_copy_(0, idx, expert_fn(rank * per_rank + le, recv_x.index_select(0, idx)))
-  if world == 1:
+  if not exchange:
     back = recv_y
   else:
     back = torch.empty_like(sorted_x)

@@ -54,6 +54,24 @@ class OpContext:
     _lib.check(self.lib.ixt_op_rope(self.ctx, _vp(x), _vp(pos), x.shape[0], nheads, _stream()))
     return x
 
+  def moe_route(self, layer: int, x: torch.Tensor):
+    """x bf16 [R, emb] -> (experts int32 [R, k] in top_k order, weights f32 [R, k])."""
+    R, K = x.shape[0], int(self.config.num_experts_per_tok)
+    experts = torch.empty((R, K), dtype=torch.int32, device=x.device)
+    weights = torch.empty((R, K), dtype=torch.float32, device=x.device)
+    _lib.check(self.lib.ixt_op_moe_route(self.ctx, layer, _vp(x), R, _vp(experts), _vp(weights), _stream()))
+    return experts, weights
+
+  def moe_expert(self, layer: int, expert: int, x: torch.Tensor) -> torch.Tensor:
+    out = torch.empty_like(x)
+    _lib.check(self.lib.ixt_op_moe_expert(self.ctx, layer, int(expert), _vp(x), x.shape[0], _vp(out), _stream()))
+    return out
+
+  def moe_combine(self, y: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
+    out = torch.empty((y.shape[0], y.shape[2]), dtype=y.dtype, device=y.device)
+    _lib.check(self.lib.ixt_op_moe_combine(self.ctx, _vp(y), _vp(weights), y.shape[0], _vp(out), _stream()))
+    return out
+
   def swiglu(self, a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(a)
     _lib.check(self.lib.ixt_op_swiglu(self.ctx, _vp(a), _vp(b), _vp(out), a.numel(), _stream()))

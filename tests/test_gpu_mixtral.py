@@ -69,3 +69,40 @@ def test_mixtral_8x7b_widths():
   w = H.synth.synth_weights(cfg, 10)
   prompts = [(_prompt(cfg.vocab_size, 16, 80 + s), [13, 6][s]) for s in range(2)]
   run_pair(cfg, w, prompts, steps=3)
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_routed_moe_module_with_exchange_matches_oracle(rccl):
+  """layers.moe.RoutedMoE over the op-level entry points (route -> exchange -> per-expert MLP -> exchange -> combine) against the oracle's
+  mixture, bit for bit; rccl=True runs the two all-to-alls on a one-rank RCCL group (the expert-parallel code path on this one-GPU box)."""
+  import ctypes
+  import importlib
+  import torch
+  import torch.distributed as dist
+  from oracle import oracle as O
+  cfg = _cfg(max_prefill_predict_length=64)
+  w = H.synth.synth_weights(cfg, 12)
+  eng, _ = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  moe = importlib.import_module("maxtext-indextts2_amd.layers.moe")
+  rng = np.random.default_rng(3)
+  R, E = 37, cfg.emb_dim
+  xn = H.synth.f32_to_bf16_bits(rng.standard_normal((R, E)).astype(np.float32))
+  want = np.zeros((R, E), np.uint16)
+  routing = np.zeros((R, 2), np.int32)
+  O.lib().orc_moe_rows(ctypes.byref(orc.model.c), 1, xn.ctypes.data_as(O._u16p), R, want.ctypes.data_as(O._u16p), routing.ctypes.data_as(O._i32p))
+  started = False
+  if rccl and not dist.is_initialized():
+    port = H.free_port() if hasattr(H, "free_port") else 29611
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    started = True
+  try:
+    m = moe.get_routed_moe(cfg, cfg.num_experts, cfg.num_experts_per_tok, engine=eng, layer=1, always_exchange=rccl)
+    out, loss = m(H.dev_bf16(xn).reshape(1, R, E))
+    torch.cuda.synchronize()
+    assert loss is None and np.array_equal(H.bits(out.reshape(R, E)), want)
+    experts, _ = m.ctx.moe_route(1, H.dev_bf16(xn))
+    assert np.array_equal(experts.cpu().numpy(), routing)
+  finally:
+    if started:
+      dist.destroy_process_group()
