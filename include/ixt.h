@@ -135,6 +135,9 @@ int ixt_pages_copy(ixt_ctx* ctx, int src_group, int dst_slot, int length, void* 
  * last reset, the last group that failed, decode rows left without a page, packed prefill rows at or beyond their call's max_len};
  * synchronises `stream`; reset != 0 clears the counters. */
 int ixt_pages_status(ixt_ctx* ctx, int32_t* out4, int reset, void* stream);
+/* The same four words copied to PINNED host memory in stream order, without waiting: the caller records an event behind the call and reads
+ * the words once it has completed (a throughput path checks the reservations of packed prefill N while pass N already runs). */
+int ixt_pages_status_async(ixt_ctx* ctx, int32_t* host_out4, void* stream);
 /* Copy the seven PageState fields to HOST arrays (synchronises `stream`); the decode slots' groups only:
  * page_status[num_pages], page_map[max_slots*max_pages_per_group], num_pages_used[max_slots],
  * sequence_lengths[max_slots], active_page[max_slots], has_active_page[max_slots] (0/1),

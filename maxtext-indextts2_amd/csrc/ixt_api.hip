@@ -581,6 +581,11 @@ extern "C" int ixt_pages_status(ixt_ctx* c, int32_t* out4, int reset, void* stre
   if (reset) HIPCHK(hipMemsetAsync(c->ps.status, 0, sizeof(int32_t) * 4, st));
   return IXT_OK;
 }
+extern "C" int ixt_pages_status_async(ixt_ctx* c, int32_t* host_out4, void* stream) {
+  if (!c || !host_out4) return set_err(IXT_ERR_INVALID, "null argument");
+  HIPCHK(hipMemcpyAsync(host_out4, c->ps.status, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return IXT_OK;
+}
 #ifndef IXT_SOURCE_HASH
 #define IXT_SOURCE_HASH "unhashed"
 #endif

@@ -127,6 +127,35 @@ class MaxEngine(engine_api.Engine):
     self._result = torch.zeros((B, 3), dtype=torch.int32, device=self.device)
     self._first = torch.zeros((1,), dtype=torch.int32, device=self.device)
     self._page_failures = 0
+    self._status_host = torch.zeros((4,), dtype=torch.int32).pin_memory()   # deferred reservation check of the packed prefill
+    self._status_event = None
+    self._status_what = ""
+
+  def _raise_if_new_failure(self, failures: int, group: int, what: str) -> None:
+    if failures != self._page_failures:
+      self._page_failures = failures
+      raise ValueError(f"{what}: the page pool (pagedattn_num_pages={self.config.pagedattn_num_pages}) could not serve the reservation "
+                       f"of page group {group}; the group holds no pages")
+
+  def _snapshot_pages(self, what: str) -> None:
+    """The throughput form of _check_pages: the status words are copied to pinned memory in stream order and looked at by the next engine
+    call (`insert_partial`, which hands the pages on, at the latest) -- the host does not wait here, so the pass this call enqueues
+    starts right behind the previous one."""
+    if not self.config.ixt_check_pages:
+      return
+    self._settle_pages()
+    _lib.check(self.lib.ixt_pages_status_async(self._ctx, ctypes.c_void_p(self._status_host.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    self._status_event, self._status_what = ev, what
+
+  def _settle_pages(self) -> None:
+    ev = self._status_event
+    if ev is None:
+      return
+    self._status_event = None
+    ev.synchronize()
+    self._raise_if_new_failure(int(self._status_host[0]), int(self._status_host[1]), self._status_what)
 
   def _check_pages(self, what: str) -> None:
     """The reference's page manager leaves a group empty, silently, when the pool cannot serve a reservation
@@ -134,12 +163,10 @@ class MaxEngine(engine_api.Engine):
     unless ixt_check_pages is off, the call that asked for the pages raises."""
     if not self.config.ixt_check_pages:
       return
+    self._settle_pages()
     out = (ctypes.c_int32 * 4)()
     _lib.check(self.lib.ixt_pages_status(self._ctx, out, 0, ctypes.c_void_p(_stream_ptr())))
-    if out[0] != self._page_failures:
-      self._page_failures = out[0]
-      raise ValueError(f"{what}: the page pool (pagedattn_num_pages={self.config.pagedattn_num_pages}) could not serve the reservation "
-                       f"of page group {out[1]}; the group holds no pages")
+    self._raise_if_new_failure(out[0], out[1], what)
 
   def __del__(self):
     try:
@@ -293,7 +320,7 @@ class MaxEngine(engine_api.Engine):
     B = self._B
     for i, l in enumerate(lens):
       self.page_state = self.page_manager.update_prefill_pages(page_state=self.page_state, page_group_id=B + i, true_length=l, _staging=True)
-    self._check_pages("prefill_concat")
+    self._snapshot_pages("prefill_concat")
     idx = torch.cat([torch.arange(st, st + l, device=self.device) for st, l in zip(starts, lens)])
     row_tok = toks[idx].contiguous()
     row_pos = pos_all[idx].contiguous()
@@ -323,6 +350,7 @@ class MaxEngine(engine_api.Engine):
   def generate(self, params: Params, decode_state: DecodeState, sampler: Any = None, rng: Any = None) -> Tuple[DecodeState, engine_api.ResultTokens]:
     """maxengine.py:838-936: page advance + one token for all slots + state update, in one library call."""
     del params, sampler, rng
+    self._settle_pages()
     lg = decode_state.get("logits")
     if self.config.return_log_prob and not isinstance(lg, torch.Tensor):     # the log-probabilities are taken from the step's rounded logits
       lg = torch.empty((self._B, 1, self.config.vocab_size), dtype=torch.float32, device=self.device)
@@ -372,6 +400,7 @@ class MaxEngine(engine_api.Engine):
     del start_indices, seq_len
     if not isinstance(cache, PagedCacheHandle) or cache.groups is None:
       raise ValueError("insert_partial: `cache` must be the handle returned by prefill_concat")
+    self._settle_pages()       # a reservation of the packed prefill that the pool could not serve surfaces here, before its pages move
     n = int(num_prompts)
     slot_list = [int(v) for v in _host_ints(slots)[:n]]
     if n > len(cache.groups) or len(slot_list) < n:

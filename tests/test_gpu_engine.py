@@ -521,3 +521,30 @@ def test_return_log_prob_outputs():
     eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=2, return_prompt_logp=True)
   del eng
   torch.cuda.synchronize()
+
+
+def test_packed_prefill_pool_shortage_surfaces_before_the_pages_move():
+  """prefill_concat checks its reservations without stopping the host (the status words travel to pinned memory in stream order); a reservation
+  the pool could not serve raises from insert_partial, before any page list is handed to a slot, and the served prompts' results stand."""
+  import torch
+  cfg = H.make_config(per_device_batch_size=3.0, pagedattn_num_pages=6, pagedattn_tokens_per_page=8, ixt_staging_groups=2, ixt_max_packed_rows=64)
+  w = H.synth.synth_weights(cfg, 15)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  t0 = H.synth.synth_prompt(cfg.vocab_size, 32, 4)[0]
+  t1 = H.synth.synth_prompt(cfg.vocab_size, 32, 5)[0]
+  lens = np.array([20, 30], np.int32)                 # 3 pages + 4 pages, 5 usable
+  starts = np.array([0, 20], np.int32)
+  toks = np.concatenate([t0[:20], t1[:30]]).astype(np.int32)
+  pos = np.concatenate([np.arange(20), np.arange(30)]).astype(np.int32)
+  seg = np.concatenate([np.full(20, 1), np.full(30, 2)]).astype(np.int32)
+  cache, pres, results = eng.prefill_concat(params=params, padded_tokens=toks, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts,
+                                            true_lengths=lens, num_prompts=2)
+  _, ores = orc.prefill(t0, 20, slot=0)
+  assert int(results[0].data.cpu().numpy()[0, 0]) == int(ores[0, 0])          # the prompt that got its pages was computed
+  with pytest.raises(ValueError, match="prefill_concat.*page pool"):
+    eng.insert_partial(pres, eng.init_decode_state(), cache, [0, 1], num_prompts=2)
+  ds = eng.insert_partial(pres, eng.init_decode_state(), cache, [0], num_prompts=1)   # the failure was reported once; the served prompt inserts
+  ds, r = eng.generate(params, ds)
+  torch.cuda.synchronize()
+  assert int(r.data.cpu().numpy()[0, 1]) == 1
