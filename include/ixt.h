@@ -153,6 +153,10 @@ int ixt_pages_import_status(ixt_ctx* ctx, const int32_t* page_status, void* stre
  * rows = tokens_dev[0..n_tokens) at positions start_pos.., K/V written in place to the slot's pages,
  * first_token_dev[0] = argmax of the last row's logits (:483-499).  last_logits_dev (f32[vocab]) may be
  * NULL.  n_tokens is the TRUE length of the chunk (padding rows are never computed). */
+/* `return_prompt_logp` of MaxEngine._prefill_jit (maxengine.py:477-478): prompt_logp_dev f32[n_tokens] = log_softmax(logits[t])[tokens[t]] for
+ * every row t of the chunk that the LAST ixt_prefill_chunk call on this ctx ran (same tokens_dev / n_tokens, nothing in between); the rows
+ * are unembedded max(max_slots, staging_groups) at a time into a workspace allocated on the first call. */
+int ixt_prefill_prompt_logp(ixt_ctx* ctx, const int32_t* tokens_dev, int n_tokens, float* prompt_logp_dev, void* stream);
 int ixt_prefill_chunk(ixt_ctx* ctx, int slot, const int32_t* tokens_dev, int n_tokens, int start_pos,
                       int32_t* first_token_dev, float* last_logits_dev, void* stream);
 /* MaxEngine.prefill_concat's model pass (maxengine.py:719-836) over pages: n_rows rows of several prompts as one ragged batch -- row i =

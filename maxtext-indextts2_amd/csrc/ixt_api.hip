@@ -113,6 +113,11 @@ struct ixt_ctx {
   float pv_cap = 0.0f;       // soft cap / window of the attention launch being issued (k_attn_pv)
   int pv_window = 0;
   float* glogits = nullptr;  // [NLmax][V] logits rows when the caller asks for none (the cap and the sampling need them)
+  // return_prompt_logp (ixt_prefill_prompt_logp): the hidden rows the last forward pass left behind, and a logits workspace made on first use
+  const bf16_t* h_final = nullptr;
+  int h_final_rows = 0;
+  float* plogits = nullptr;     // [NLmax][V]
+  int32_t* pargmax = nullptr;   // [NLmax]
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
   // graphs keyed by the pointer tuple of ixt_generate
@@ -1163,6 +1168,7 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
       LAUNCHCHK();
     }
   }
+  c->h_final = hcur; c->h_final_rows = R;
   return IXT_OK;
 }
 
@@ -1306,6 +1312,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     if (!final_fused) TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, lrows ? hcur : hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st, 1, lrows));
     TRY(launch_unembed(c, c->xn, nl, logits_out, argmax_out, st));
   }
+  c->h_final = hcur; c->h_final_rows = R;
   return IXT_OK;
 }
 
@@ -1320,6 +1327,36 @@ extern "C" int ixt_prefill_chunk(ixt_ctx* c, int slot, const int32_t* tokens_dev
                      c->ps.num_pages_used, c->P);
   LAUNCHCHK();
   return forward_rows(c, n_tokens, tokens_dev, start_pos + n_tokens, n_tokens - 1, 1, nullptr, first_token_dev, last_logits_dev, false, st);
+}
+
+// maxengine.py:477-478 (`return_prompt_logp`): log_softmax(logits[t])[tokens[t]] of every row t of the chunk the last ixt_prefill_chunk call
+// ran.  The pass leaves the rows' final hidden states behind; they are normalised and unembedded here NLmax rows at a time (the logits of a
+// 256-row chunk at V = 264 192 are 270 MB: they never exist as a whole).
+extern "C" int ixt_prefill_prompt_logp(ixt_ctx* c, const int32_t* tokens_dev, int n_tokens, float* prompt_logp_dev, void* stream) {
+  if (!c || !tokens_dev || !prompt_logp_dev) return set_err(IXT_ERR_INVALID, "null argument");
+  if (c->h_final == nullptr || n_tokens <= 0 || n_tokens != c->h_final_rows)
+    return set_err(IXT_ERR_INVALID, "prompt log-probabilities: call right after ixt_prefill_chunk with the same n_tokens (%d rows are held)", c->h_final_rows);
+  hipStream_t st = (hipStream_t)stream;
+  if (c->plogits == nullptr) {
+    TRY(dmalloc(c, &c->plogits, (size_t)c->NLmax * c->V));
+    TRY(dmalloc(c, &c->pargmax, (size_t)c->NLmax));
+  }
+  const ixt_config& cf = c->cfg;
+  for (int row0 = 0; row0 < n_tokens; row0 += c->NLmax) {
+    const int g = n_tokens - row0 < c->NLmax ? n_tokens - row0 : c->NLmax;
+    TRY(launch_rownorm(c, 2, g, nullptr, nullptr, c->h_final + (size_t)row0 * c->E, nullptr, c->final_norm, c->xn, st));
+    TRY(launch_unembed(c, c->xn, g, c->plogits, c->pargmax, st));
+    if (c->gemma) {   // decoders.py:552-565
+      const int normalize = cf.logits_via_embedding && cf.normalize_embedding_logits;
+      const float cap = cf.logits_via_embedding ? cf.final_logits_soft_cap : 0.0f;
+      if (normalize || cap > 0.0f) {
+        hipLaunchKernelGGL(k_logits_post, dim3(g), dim3(256), 0, st, c->plogits, c->V, normalize, sqrtf((float)c->E), cap, c->sample_cols, c->pargmax);
+        LAUNCHCHK();
+      }
+    }
+    TRY(ixt_op_logprob(c, c->plogits, g, tokens_dev + row0, prompt_logp_dev + row0, stream));
+  }
+  return IXT_OK;
 }
 
 extern "C" int ixt_prefill_rows(ixt_ctx* c, int n_rows, const int32_t* tokens_dev, const int32_t* row_group_dev, const int32_t* row_pos_dev, int max_len,

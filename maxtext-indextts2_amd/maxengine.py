@@ -236,8 +236,6 @@ class MaxEngine(engine_api.Engine):
     del params, sampler, rng, request_id
     if images is not None:
       raise NotImplementedError("multimodal prefill is outside the built path")
-    if return_prompt_logp:
-      raise NotImplementedError("return_prompt_logp needs the logits of every prompt row; only the last row's are computed here")
     if slot is None:
       slot = 0
     true_length = int(true_length)
@@ -259,6 +257,11 @@ class MaxEngine(engine_api.Engine):
     first = torch.empty((1, 1), dtype=torch.int32, device=self.device)
     _lib.check(self.lib.ixt_prefill_chunk(self._ctx, slot, ctypes.c_void_p(toks.data_ptr()), true_length, start,
                                           ctypes.c_void_p(first.data_ptr()), ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    prompt_logp = None
+    if return_prompt_logp:     # maxengine.py:477-478: log_softmax(logits[t])[tokens[t]] per position; positions past true_length (padding) hold 0
+      prompt_logp = torch.zeros((1, toks.numel()), dtype=torch.float32, device=self.device)
+      _lib.check(self.lib.ixt_prefill_prompt_logp(self._ctx, ctypes.c_void_p(toks.data_ptr()), true_length, ctypes.c_void_p(prompt_logp.data_ptr()),
+                                                  ctypes.c_void_p(_stream_ptr())))
     generated = torch.zeros((1, 1), dtype=torch.int32, device=self.device)
     data = torch.cat([first, torch.ones_like(first), generated], dim=1)
     token_logp = self._token_logp(logits, first) if self.config.return_log_prob else None     # maxengine.py:502-505
@@ -270,7 +273,7 @@ class MaxEngine(engine_api.Engine):
         "next_pos": next_pos,
         "generated_tokens": generated,
         "tokens": first,
-        "prompt_logp": None,
+        "prompt_logp": prompt_logp,
     }
     return prefix, result
 

@@ -549,7 +549,7 @@ class OracleEngine:
     arr = np.array([v for r in ranges for v in r] or [0], np.int32)
     lib().orc_set_sampling_ranges(_p(arr, _i32p), len(ranges))
 
-  def prefill(self, padded_tokens, true_length, slot=0, existing_prefix_tokens=None, want_logits=False):
+  def prefill(self, padded_tokens, true_length, slot=0, existing_prefix_tokens=None, want_logits=False, want_prompt_logp=False):
     start = 0 if existing_prefix_tokens is None else len(existing_prefix_tokens)
     if start == 0:
       self.page_state = self.pm.update_prefill_pages(self.page_state, slot, true_length)
@@ -558,10 +558,17 @@ class OracleEngine:
     n = int(true_length)
     toks = np.asarray(padded_tokens, np.int32)[:n]
     pos = np.arange(start, start + n, dtype=np.int32)
-    out = self.model.forward(toks, np.full((n,), slot, np.int32), pos, np.ones((n,), np.int32), self.page_state.page_map,
-                             logits_rows=[n - 1], want_logits=want_logits)
+    prompt_logp = None
+    if want_prompt_logp:   # maxengine.py:477-478: log_softmax(logits[t])[tokens[t]] for every row of the chunk
+      out = self.model.forward(toks, np.full((n,), slot, np.int32), pos, np.ones((n,), np.int32), self.page_state.page_map,
+                               logits_rows=list(range(n)), want_logits=True)
+      prompt_logp = logprob_rows(out["logits"], toks)
+      out = {"argmax": out["argmax"][n - 1:], "logits": out["logits"][n - 1:] if want_logits else None}
+    else:
+      out = self.model.forward(toks, np.full((n,), slot, np.int32), pos, np.ones((n,), np.int32), self.page_state.page_map,
+                               logits_rows=[n - 1], want_logits=want_logits)
     first = int(out["argmax"][0])
-    prefix = {"logits": out["logits"], "next_pos": np.full((1, 1), start + n, np.int32),
+    prefix = {"logits": out["logits"], "next_pos": np.full((1, 1), start + n, np.int32), "prompt_logp": prompt_logp,
               "generated_tokens": np.zeros((1, 1), np.int32), "tokens": np.full((1, 1), first, np.int32), "slot": slot}
     result = np.array([[first, 1, 0]], np.int32)
     return prefix, result

@@ -517,8 +517,42 @@ def test_return_log_prob_outputs():
   want = O.logprob_rows(lg, pres["tokens"].reshape(2).cpu().numpy())
   got = np.concatenate([r.log_prob.cpu().numpy().reshape(-1) for r in results])
   assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-  with pytest.raises(NotImplementedError):
-    eng.prefill(params=params, padded_tokens=toks, true_length=tl, slot=2, return_prompt_logp=True)
+  with pytest.raises(NotImplementedError):      # the packed form is not built
+    eng.prefill_concat(params=params, padded_tokens=t2, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts, true_lengths=ln, num_prompts=2,
+                       return_prompt_logp=True)
+  del eng
+  torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("model,slots", [("ixt-tiny", 1), ("ixt-tiny", 7), ("gemma2-tiny", 2), ("mixtral-tiny", 3)])
+def test_return_prompt_logp(model, slots):
+  """prefill(return_prompt_logp=True) (maxengine.py:477-478, 529): log_softmax(logits[t])[tokens[t]] for every prompt position, bit-exact against
+  the oracle (all rows' logits, inference_utils.log_prob_of_chosen_token restated); also chunk by chunk, where each chunk returns its own
+  positions, and with the rows unembedded 1, 2, 3 or 7 at a time (the workspace holds max_slots rows)."""
+  import torch
+  cfg = H.make_config(model, per_device_batch_size=float(slots), max_prefill_predict_length=32, max_target_length=96, use_chunked_prefill=True,
+                      prefill_chunk_size=32, pagedattn_num_pages=64)
+  w = H.synth.synth_weights(cfg, 21)
+  eng, params = H.make_engine(cfg, w)
+  orc = H.make_oracle(cfg, w)
+  toks = np.random.Generator(np.random.PCG64(5)).integers(1, cfg.vocab_size, size=64).astype(np.int32)
+  first = np.zeros((32,), np.int32)
+  first[:29] = toks[:29]
+  pre, res = eng.prefill(params=params, padded_tokens=first, true_length=29, slot=0, return_prompt_logp=True)
+  opre, ores = orc.prefill(first, 29, slot=0, want_logits=True, want_prompt_logp=True)
+  got = pre["prompt_logp"].cpu().numpy()
+  assert got.shape == (1, 32) and np.all(got[0, 29:] == 0.0)
+  assert np.array_equal(got[0, :29].view(np.uint32), opre["prompt_logp"].view(np.uint32))
+  assert np.array_equal(res.data.cpu().numpy(), ores) and np.array_equal(pre["logits"].cpu().numpy().reshape(-1).view(np.uint32), opre["logits"].reshape(-1).view(np.uint32))
+  assert np.all(got[0, :29] < 0.0)
+  # second chunk of the same sequence (positions 29 .. 52)
+  maxengine = H.importlib.import_module("maxtext-indextts2_amd.maxengine")
+  nxt = np.zeros((32,), np.int32)
+  nxt[:24] = toks[29:53]
+  ep = maxengine.ExistingPrefix(cache=pre["cache"], common_prefix_tokens=torch.from_numpy(toks[:29].copy()))
+  pre2, _ = eng.prefill(params=params, padded_tokens=nxt, true_length=24, slot=0, existing_prefix=ep, return_prompt_logp=True)
+  opre2, _ = orc.prefill(nxt, 24, slot=0, existing_prefix_tokens=toks[:29], want_prompt_logp=True)
+  assert np.array_equal(pre2["prompt_logp"].cpu().numpy()[0, :24].view(np.uint32), opre2["prompt_logp"].view(np.uint32))
   del eng
   torch.cuda.synchronize()
 
