@@ -10,6 +10,7 @@ from .. import runtime
 from ..common_types import MODEL_MODE_PREFILL
 from .linears import dense_general
 from .llama2 import LlamaDecoderLayer
+from .mixtral import MixtralDecoderLayer
 from .normalizations import rms_norm
 
 
@@ -17,11 +18,12 @@ class Decoder:
   def __init__(self, config: Any, shared_embedding: Any, mesh: Any = None, quant: Any = None, model_mode: str = MODEL_MODE_PREFILL):
     del mesh, model_mode
     cfg = config
-    if cfg.decoder_block not in ("llama2", "default") or cfg.logits_via_embedding:
-      raise NotImplementedError("Decoder: llama2 blocks with untied logits are built")
+    if cfg.decoder_block not in ("llama2", "default", "mixtral") or cfg.logits_via_embedding:
+      raise NotImplementedError("Decoder: llama2 and mixtral blocks with untied logits are built as modules (gemma2 / gemma3: engine only)")
     self.config, self.shared_embedding = cfg, shared_embedding
     self.ctx = runtime.context(cfg)
-    self.layers = [LlamaDecoderLayer(cfg, quant=quant, name=f"layers_{i}", layer_idx=i) for i in range(cfg.num_decoder_layers)]
+    block = MixtralDecoderLayer if cfg.decoder_block == "mixtral" else LlamaDecoderLayer      # decoders.py:330-360
+    self.layers = [block(cfg, quant=quant, name=f"layers_{i}", layer_idx=i) for i in range(cfg.num_decoder_layers)]
     self.decoder_norm = rms_norm(num_features=cfg.emb_dim, epsilon=cfg.normalization_layer_epsilon, name="decoder_norm", config=cfg)
     self.logits_dense = dense_general(inputs_shape=(1, 1, cfg.emb_dim), out_features_shape=cfg.vocab_size, name="logits_dense", config=cfg)
 

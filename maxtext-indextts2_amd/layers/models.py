@@ -36,6 +36,10 @@ class Transformer:
       a.key.kernel = cv(params[p + "self_attention/key/kernel"], (c.emb_dim, c.num_kv_heads, c.head_dim))
       a.value.kernel = cv(params[p + "self_attention/value/kernel"], (c.emb_dim, c.num_kv_heads, c.head_dim))
       a.out.kernel = cv(params[p + "self_attention/out/kernel"], (c.num_query_heads, c.head_dim, c.emb_dim))
+      if c.decoder_block == "mixtral":
+        layer.post_self_attention_layer_norm.scale = cv(params[p + "post_self_attention_layer_norm/scale"], (c.emb_dim,))
+        layer.MoeBlock_0.load_params(params, p + "MoeBlock_0/")
+        continue
       norm_key = p + "mlp/mlp_layer_norm/scale"
       if norm_key not in params:
         norm_key = p + "post_self_attention_layer_norm/scale"      # the converters' spelling (llama_or_mistral_ckpt.py:449-450)

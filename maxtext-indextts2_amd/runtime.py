@@ -54,6 +54,15 @@ class OpContext:
     _lib.check(self.lib.ixt_op_rope(self.ctx, _vp(x), _vp(pos), x.shape[0], nheads, _stream()))
     return x
 
+  def load_weight(self, name: str, array: Any) -> None:
+    """One leaf of the MaxText parameter tree into the context (ixt_load_weight): the kernels a module cannot carry as a plain tensor because
+    the library keeps them in its own layout (the experts of a Mixtral block)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    t = as_bf16(array, dev)
+    shape = (ctypes.c_int64 * t.dim())(*t.shape)
+    _lib.check(self.lib.ixt_load_weight(self.ctx, name.encode(), _vp(t), _lib.IXT_BF16, shape, t.dim(), _stream()))
+    torch.cuda.current_stream().synchronize()
+
   def moe_route(self, layer: int, x: torch.Tensor):
     """x bf16 [R, emb] -> (experts int32 [R, k] in top_k order, weights f32 [R, k])."""
     R, K = x.shape[0], int(self.config.num_experts_per_tok)

@@ -106,3 +106,58 @@ def test_routed_moe_module_with_exchange_matches_oracle(rccl):
   finally:
     if started:
       dist.destroy_process_group()
+
+
+def test_mixtral_transformer_from_modules_expert_parallel_path():
+  """models.Transformer / decoders.Decoder / mixtral.MixtralDecoderLayer / moe.RoutedMoE assembled from the modules, the experts reached through
+  the expert-parallel exchange (the two all-to-alls on a one-rank RCCL group): prefill logits of every row of two prompts and three decode
+  steps against the oracle, bit for bit -- the launch sequence an expert-parallel decode over N GPUs runs on each rank."""
+  import importlib
+  import torch
+  import torch.distributed as dist
+  runtime = importlib.import_module("maxtext-indextts2_amd.runtime")
+  layers_models = importlib.import_module("maxtext-indextts2_amd.layers.models")
+  ct = importlib.import_module("maxtext-indextts2_amd.common_types")
+  cfg = H.make_config("mixtral-tiny", per_device_batch_size=3.0, max_prefill_predict_length=32, max_target_length=64, pagedattn_num_pages=64)
+  w = H.synth.synth_weights(cfg, 21)
+  orc = H.make_oracle(cfg, w)
+  saved = runtime._default
+  ctx = runtime.set_context(runtime.OpContext(cfg))
+  started = False
+  if not dist.is_initialized():
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    started = True
+  try:
+    model = layers_models.Transformer(cfg, model_mode=ct.MODEL_MODE_PREFILL)
+    for layer in model.decoder.layers:
+      layer.MoeBlock_0.always_exchange = True
+    model.load_params(w)
+    pm = ctx.page_manager
+    prompts = [(_prompt(cfg.vocab_size, 32, 900), 27), (_prompt(cfg.vocab_size, 32, 901), 9)]
+    nxt = []
+    for slot, (toks, tl) in enumerate(prompts):
+      ps = pm.update_prefill_pages(None, slot, tl)
+      t = torch.from_numpy(toks[:tl][None]).cuda()
+      pos = torch.arange(tl, dtype=torch.int32, device="cuda")[None]
+      logits = model(t, pos, decoder_segment_ids=torch.ones((1, tl), dtype=torch.int32, device="cuda"), model_mode=ct.MODEL_MODE_PREFILL, slot=slot, page_state=ps)
+      orc.page_state = orc.pm.update_prefill_pages(orc.page_state, slot, tl)
+      o = orc.model.forward(toks[:tl], np.full((tl,), slot, np.int32), np.arange(tl, dtype=np.int32), np.ones((tl,), np.int32), orc.page_state.page_map,
+                            logits_rows=list(range(tl)), want_logits=True)
+      assert np.array_equal(logits[0].cpu().numpy().view(np.uint32), o["logits"].view(np.uint32)), slot
+      nxt.append(int(o["argmax"][-1]))
+    B = int(cfg.per_device_batch_size)
+    tok = np.zeros((B,), np.int32)
+    tok[:2] = nxt
+    for step in range(3):
+      ps = pm.update_decode_pages(None)
+      orc.page_state = orc.pm.update_decode_pages(orc.page_state)
+      pos = np.maximum(orc.page_state.sequence_lengths - 1, 0).astype(np.int32)
+      logits = model(torch.from_numpy(tok[:, None]).cuda(), torch.from_numpy(pos[:, None]).cuda(), model_mode=ct.MODEL_MODE_AUTOREGRESSIVE, page_state=ps)
+      act = orc.page_state.has_active_page.astype(np.int32)
+      o = orc.model.forward(tok, np.arange(B, dtype=np.int32), pos, act, orc.page_state.page_map, logits_rows=list(range(B)), want_logits=True)
+      assert np.array_equal(logits[:, 0].cpu().numpy()[:2].view(np.uint32), o["logits"][:2].view(np.uint32)), step
+      tok[:2] = o["argmax"][:2]
+  finally:
+    if started:
+      dist.destroy_process_group()
+    runtime._default = saved
