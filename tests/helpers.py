@@ -66,6 +66,13 @@ def make_engine(cfg, weights):
   return eng, params
 
 
+def free_port():
+  import socket
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
 def bits(t):
   """torch bf16 tensor -> numpy uint16 bit patterns."""
   import torch

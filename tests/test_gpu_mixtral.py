@@ -93,8 +93,7 @@ def test_routed_moe_module_with_exchange_matches_oracle(rccl):
   O.lib().orc_moe_rows(ctypes.byref(orc.model.c), 1, xn.ctypes.data_as(O._u16p), R, want.ctypes.data_as(O._u16p), routing.ctypes.data_as(O._i32p))
   started = False
   if rccl and not dist.is_initialized():
-    port = H.free_port() if hasattr(H, "free_port") else 29611
-    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{H.free_port()}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     started = True
   try:
     m = moe.get_routed_moe(cfg, cfg.num_experts, cfg.num_experts_per_tok, engine=eng, layer=1, always_exchange=rccl)
@@ -125,7 +124,7 @@ def test_mixtral_transformer_from_modules_expert_parallel_path():
   ctx = runtime.set_context(runtime.OpContext(cfg))
   started = False
   if not dist.is_initialized():
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29613", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{H.free_port()}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     started = True
   try:
     model = layers_models.Transformer(cfg, model_mode=ct.MODEL_MODE_PREFILL)
