@@ -7,8 +7,8 @@ sizes -- RCCL over xGMI on a GPU node ("nccl" backend), gloo in the CPU tests; t
 the 8 fully connected GPUs of an MI355X node an all-to-all keeps all 7 links of a GPU busy at once (each peer gets its own slice), which is
 the collective shape xGMI wants; nothing here is a ring.
 
-`get_all_to_all_params` and `permute` restate the reference's integer bookkeeping (same argument meaning and results; numpy instead of
-jnp) and are pinned by the cases the reference's own tests hold (tests/moe_test.py:788-900), restated in tests/test_moe_ep_cpu.py.  The
+`get_all_to_all_params`, `permute` and `local_permute` restate the reference's integer bookkeeping (same argument meaning and results; numpy instead of
+jnp) and are pinned by the cases the reference's own tests hold (tests/moe_test.py:634-900), restated in tests/test_moe_ep_cpu.py.  The
 expert MLP itself is the caller's function (on a GPU: the context's per-expert dots), so this module is plumbing: device memory in, device
 memory out, no arithmetic beyond the exchange."""
 from __future__ import annotations
@@ -50,54 +50,73 @@ def permute(selected_experts: torch.Tensor, num_experts: int) -> Tuple[torch.Ten
   return order, rows, group_size
 
 
+def local_permute(inputs: torch.Tensor, global_group_sizes: torch.Tensor, local_expert_size: int, shard_index: int, is_offset: bool = False,
+                  global_sorted_experts: torch.Tensor | None = None):
+  """layers/moe.py:485-568: the rows an expert shard holds, grouped by its local expert id.  `global_group_sizes` [batch shards, num_experts] =
+  copies every batch shard made for every expert.  is_offset=False: `inputs` are what the all-to-all delivered -- source shard by source
+  shard, inside a source by local expert.  is_offset=True: `inputs` are all copies sorted by global expert id (`global_sorted_experts`); rows
+  of other shards' experts sort behind this shard's.  Returns (sorted_inputs, sorted_indices, local_group_size, sorted_experts_ids)."""
+  g = global_group_sizes.reshape(-1, global_group_sizes.shape[-1])
+  local = g[:, shard_index * local_expert_size:(shard_index + 1) * local_expert_size]
+  local_group_size = local.sum(dim=0)
+  if is_offset:
+    owner = torch.div(global_sorted_experts, local_expert_size, rounding_mode="floor")
+    expert_indices = torch.where(owner == shard_index, torch.remainder(global_sorted_experts, local_expert_size),
+                                 torch.full_like(global_sorted_experts, local_expert_size))
+  else:
+    sizes = local.reshape(-1)
+    base = torch.remainder(torch.arange(sizes.shape[0], device=sizes.device), local_expert_size)
+    expert_indices = torch.repeat_interleave(base, sizes)
+    pad = inputs.shape[0] - expert_indices.shape[0]          # jnp.repeat(total_repeat_length=...): pad with the last value / cut
+    if pad > 0:
+      expert_indices = torch.cat([expert_indices, expert_indices[-1:].expand(pad) if expert_indices.numel() else expert_indices.new_zeros(pad)])
+    expert_indices = expert_indices[:inputs.shape[0]]
+  sorted_indices = torch.argsort(expert_indices, stable=True)
+  return inputs.index_select(0, sorted_indices), sorted_indices, local_group_size, expert_indices[sorted_indices]
+
+
 def expert_parallel_apply(x: torch.Tensor, selected_experts: torch.Tensor, num_experts: int,
                           expert_fn: Callable[[int, torch.Tensor], torch.Tensor], group=None, always_exchange: bool = False) -> torch.Tensor:
   """x [rows, emb] and selected_experts int [rows, k] of THIS rank -> y [rows, k, emb] with y[r, j] = expert_fn(selected_experts[r, j], x[r]),
   every expert evaluated on the rank that owns it (experts_per_rank = num_experts / world consecutive ids per rank).  expert_fn(e, rows)
   is called once per local expert that received rows, with the global expert id.  always_exchange: run the collectives on a one-rank
-  group too (exercises the RCCL calls on a one-GPU box)."""
-  world = dist.get_world_size(group) if dist.is_initialized() else 1
-  rank = dist.get_rank(group) if dist.is_initialized() else 0
+  group too (exercises the RCCL calls on a one-GPU box).  The steps are the reference's (moe.py:799-942): permute -> all-gather of the
+  group sizes -> all-to-all (get_all_to_all_params) -> local_permute -> experts -> undo -> all-to-all back -> unpermute."""
+  exchange = dist.is_initialized() and (dist.get_world_size(group) > 1 or always_exchange)
+  world = dist.get_world_size(group) if exchange else 1
+  rank = dist.get_rank(group) if exchange else 0
   if num_experts % world:
     raise ValueError(f"num_experts ({num_experts}) must be a multiple of the expert-parallel degree ({world})")
   per_rank = num_experts // world
   R, K = selected_experts.shape
   order, src_rows, group_size = permute(selected_experts, num_experts)
   sorted_x = x.index_select(0, src_rows)                               # copies grouped by expert = grouped by owning rank
-  send_counts = group_size.reshape(world, per_rank)                    # [dest rank][its local expert]
-  exchange = world > 1 or (always_exchange and dist.is_initialized())
-  if not exchange:
-    recv_counts = send_counts.clone()
-    recv_x = sorted_x
-  else:
-    recv_counts = torch.empty_like(send_counts)
-    dist.all_to_all_single(recv_counts, send_counts, group=group)      # [src rank][my local expert]
-    send_split = send_counts.sum(dim=1).tolist()
-    recv_split = recv_counts.sum(dim=1).tolist()
+  if exchange:
+    gathered = [torch.empty_like(group_size) for _ in range(world)]
+    dist.all_gather(gathered, group_size, group=group)                 # moe.py:813-816: every shard learns every shard's group sizes
+    all_sizes = torch.stack(gathered)                                  # [batch shard, expert]
+    shard_sizes = all_sizes.reshape(world, world, per_rank).sum(dim=-1).cpu().numpy()     # [batch shard, expert shard]
+    _, send_sizes, _, recv_sizes = get_all_to_all_params(shard_sizes, rank, world, is_batch_sharded=True)
+    send_split, recv_split = [int(v) for v in send_sizes], [int(v) for v in recv_sizes]
     recv_x = x.new_empty((sum(recv_split), x.shape[1]))
     dist.all_to_all_single(recv_x, sorted_x, recv_split, send_split, group=group)
-  # received rows arrive grouped by source rank, inside a source by local expert: walk the blocks, one expert_fn call per local expert
-  counts = recv_counts.tolist()
-  recv_y = torch.empty_like(recv_x)
-  starts = []
-  off = 0
-  for s in range(world):
-    row = []
-    for le in range(per_rank):
-      row.append(off)
-      off += counts[s][le]
-    starts.append(row)
-  for le in range(per_rank):
-    pieces = [(starts[s][le], counts[s][le]) for s in range(world) if counts[s][le]]
-    if not pieces:
-      continue
-    idx = torch.cat([torch.arange(a, a + n, device=x.device) for a, n in pieces])
-    recv_y.index_copy_(0, idx, expert_fn(rank * per_rank + le, recv_x.index_select(0, idx)))
-  if not exchange:
-    back = recv_y
   else:
+    all_sizes = group_size[None]
+    recv_x = sorted_x
+  local_x, local_idx, local_group_size, _ = local_permute(recv_x, all_sizes, per_rank, rank)
+  local_y = torch.empty_like(local_x)
+  off = 0
+  for le, n in enumerate(local_group_size.tolist()):
+    if n:
+      local_y[off:off + n] = expert_fn(rank * per_rank + le, local_x[off:off + n])
+      off += n
+  recv_y = torch.empty_like(local_y)
+  recv_y.index_copy_(0, local_idx, local_y)                            # moe.py:896-900: back to the order the rows arrived in
+  if exchange:
     back = torch.empty_like(sorted_x)
     dist.all_to_all_single(back, recv_y, send_split, recv_split, group=group)
+  else:
+    back = recv_y
   y = torch.empty((R * K, x.shape[1]), dtype=x.dtype, device=x.device)
   y.index_copy_(0, order, back)                                        # moe.py:455-466: undo the sort
   return y.reshape(R, K, x.shape[1])

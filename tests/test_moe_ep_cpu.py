@@ -45,6 +45,46 @@ def test_permute_matches_the_reference_rule():
   assert np.array_equal(group.numpy(), np.bincount(flat, minlength=4))
 
 
+def test_local_permute_no_offset_reference_case():
+  """tests/moe_test.py:634-712: 8 experts on 4 shards, expert e holds e rows; a shard's input slice is already in local-expert order."""
+  sizes = torch.arange(8)
+  total = int(sizes.sum())
+  original = torch.arange(total * 5, dtype=torch.int32).reshape(total, 5)
+  cum = torch.cumsum(sizes, 0)
+  for shard in range(4):
+    a = 0 if shard == 0 else int(cum[2 * shard - 1])
+    b = int(cum[2 * shard + 1])
+    si, idx, lgs, ids = ep.local_permute(original[a:b], sizes[None, :], 2, shard, is_offset=False)
+    assert torch.equal(si, original[a:b]) and torch.equal(idx, torch.arange(b - a))
+    assert torch.equal(lgs, sizes[2 * shard:2 * shard + 2])
+    assert torch.equal(ids, torch.repeat_interleave(torch.arange(2), sizes[2 * shard:2 * shard + 2]))
+
+
+def test_local_permute_offset_reference_case():
+  """tests/moe_test.py:714-786: all copies sorted by global expert id; a shard takes its slice and its experts' local ids."""
+  for counts in (torch.arange(8), torch.tensor([0, 0, 1, 1, 2, 0, 2, 2])):
+    total = int(counts.sum())
+    x = torch.arange(1, total + 1).reshape(-1, 1).repeat(1, 5)
+    local_sizes = counts.reshape(4, 2).sum(-1)
+    assign = torch.repeat_interleave(torch.arange(8), counts)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(local_sizes, 0)[:-1]])
+    for shard in range(4):
+      px, idx, lcounts, lassign = ep.local_permute(x, counts[None, :], 2, shard, is_offset=True, global_sorted_experts=assign)
+      n, o = int(local_sizes[shard]), int(offs[shard])
+      assert torch.equal(px[:n], x[o:o + n]) and torch.equal(idx[:n], torch.arange(o, o + n))
+      assert torch.equal(lcounts, counts[2 * shard:2 * shard + 2])
+      assert torch.equal(lassign[:n], torch.remainder(assign[o:o + n], 2))
+
+
+def test_local_permute_groups_what_two_sources_delivered():
+  """Rows from 2 source shards for 2 local experts arrive as [s0e0 s0e1 s1e0 s1e1]; the shard wants [e0 rows | e1 rows], sources in order."""
+  g = torch.tensor([[2, 1, 9, 9], [1, 3, 9, 9]])            # shard 0 owns experts 0, 1
+  rows = torch.arange(7).reshape(7, 1)
+  si, idx, lgs, ids = ep.local_permute(rows, g, 2, 0)
+  assert si.reshape(-1).tolist() == [0, 1, 3, 2, 4, 5, 6] and lgs.tolist() == [3, 4] and ids.tolist() == [0, 0, 0, 1, 1, 1, 1]
+  assert idx.tolist() == [0, 1, 3, 2, 4, 5, 6]
+
+
 def _expert(e, rows):
   return rows * float(e + 1) + float(e)
 
