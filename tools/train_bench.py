@@ -43,8 +43,9 @@ def main():
     print(f"[train_bench] step {i}: loss {m['learning/loss']:.4f} raw_grad_norm {m['learning/raw_grad_norm']:.4f} lr {m['learning/current_learning_rate']:.2e} "
           f"{m['step_s']:.3f} s", file=sys.stderr, flush=True)
   best = min(m["step_s"] for m in out[1:]) if steps > 1 else out[0]["step_s"]
-  # 155.4 TFLOP per step per GPU at pdb 8 x 2048 (scaled linearly in tokens for other shapes; attention term included there)
-  tflop = 155.4 * (pdb * S) / (8 * 2048)
+  # the reference's own count (maxtext_utils.calculate_tflops_training_per_device; SURVEY.md 8(d): 155.4 TFLOP per step per GPU at 8 x 2048)
+  import importlib
+  tflop = importlib.import_module("maxtext-indextts2_amd.maxtext_utils").calculate_tflops_training_per_device(cfg, log=False)[0]
   print(json.dumps({"config": f"C3 share: indextts2-1b, per_device_batch {pdb} x {S} tokens, 1 GPU", "steps": steps, "step_s": best, "tokens_per_s": pdb * S / best,
                     "tflop_per_s": tflop / best, "mfu_bf16": tflop / best / 2500.0, "losses": [m["learning/loss"] for m in out], "ln_vocab": float(np.log(cfg.vocab_size))}))
 
