@@ -44,7 +44,6 @@ def main():
           f"{m['step_s']:.3f} s", file=sys.stderr, flush=True)
   best = min(m["step_s"] for m in out[1:]) if steps > 1 else out[0]["step_s"]
   # the reference's own count (maxtext_utils.calculate_tflops_training_per_device; SURVEY.md 8(d): 155.4 TFLOP per step per GPU at 8 x 2048)
-  import importlib
   tflop = importlib.import_module("maxtext-indextts2_amd.maxtext_utils").calculate_tflops_training_per_device(cfg, log=False)[0]
   print(json.dumps({"config": f"C3 share: indextts2-1b, per_device_batch {pdb} x {S} tokens, 1 GPU", "steps": steps, "step_s": best, "tokens_per_s": pdb * S / best,
                     "tflop_per_s": tflop / best, "mfu_bf16": tflop / best / 2500.0, "losses": [m["learning/loss"] for m in out], "ln_vocab": float(np.log(cfg.vocab_size))}))
