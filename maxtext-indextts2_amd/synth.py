@@ -234,3 +234,66 @@ def synth_prompt(vocab_size: int, prefill_length: int, seed: int = 1234, n_text:
   out = np.zeros((prefill_length,), np.int32)
   out[:true_length] = ids[:true_length]
   return out, true_length
+
+
+# ----------------------------------------------------------------------------- full-size trees drawn on the device
+class DeviceTree:
+  """{MaxText tree path: bf16 CUDA tensor} for MaxEngine.load_params, each tensor drawn (truncated normal of the kernel's fan-in; norm scales 1)
+  when load_params asks for it and dropped afterwards: the 5 GB Gemma-2 2B and 93 GB Mixtral-8x7B trees load in well under a second, where the
+  host-side generator above needs minutes.  Same values for the same (spec, seed) on the same torch build; NOT the values of synth_weights."""
+
+  def __init__(self, spec, seed: int = 0):
+    self.spec, self.seed = spec, seed
+
+  def items(self):
+    import torch  # pylint: disable=import-outside-toplevel
+    g = torch.Generator(device="cuda")
+    for i, (name, shape, std) in enumerate(self.spec):
+      g.manual_seed(self.seed * 100003 + i)
+      if std is None:
+        yield name, torch.ones(shape, dtype=torch.bfloat16, device="cuda")
+      else:
+        t = torch.empty(shape, dtype=torch.float32, device="cuda").normal_(0.0, std, generator=g).clamp_(-2 * std, 2 * std)
+        yield name, t.to(torch.bfloat16)
+        del t
+
+
+def device_tree_spec(cfg):
+  """[(tree path, shape, std or None for a norm scale)] of the configured block (llama2, gemma2, mixtral)."""
+  E, Q, KV, D, F, V = cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size
+  block = getattr(cfg, "decoder_block", "llama2")
+  spec = [("params/token_embedder/embedding", (V, E), 1.0)]
+
+  def attn(p):
+    return [(p["q"], (E, Q, D), 1 / math.sqrt(E * D)), (p["k"], (E, KV, D), 1 / math.sqrt(E)), (p["v"], (E, KV, D), 1 / math.sqrt(E)),
+            (p["o"], (Q, D, E), 1 / math.sqrt(Q * D))]
+
+  for i in range(cfg.num_decoder_layers):
+    if block == "gemma2":
+      for sub in ("local", "global"):
+        p = gemma2_layer_paths(i, sub)
+        spec += [(p["ln1"], (E,), None)] + attn(p) + [(p["ln2"], (E,), None), (p["wi0"], (E, F), 1 / math.sqrt(E)), (p["wi1"], (E, F), 1 / math.sqrt(E)),
+                                                       (p["wo"], (F, E), 1 / math.sqrt(F))]
+        if getattr(cfg, "use_post_attn_norm", False):
+          spec.append((p["pan"], (E,), None))
+        if getattr(cfg, "use_post_ffw_norm", False):
+          spec.append((p["pfn"], (E,), None))
+    elif block == "mixtral":
+      p = layer_paths(i)
+      b = f"params/decoder/layers_{i}/"
+      NE = cfg.num_experts
+      spec += [(p["ln1"], (E,), None)] + attn(p) + [(b + "post_self_attention_layer_norm/scale", (E,), None), (b + "MoeBlock_0/gate/kernel", (E, NE), 4 / math.sqrt(E)),
+                                                     (b + "MoeBlock_0/wi_0", (NE, E, F), 1 / math.sqrt(E)), (b + "MoeBlock_0/wi_1", (NE, E, F), 1 / math.sqrt(E)),
+                                                     (b + "MoeBlock_0/wo", (NE, F, E), 1 / math.sqrt(F))]
+    else:
+      p = layer_paths(i)
+      spec += [(p["ln1"], (E,), None)] + attn(p) + [(p["ln2"], (E,), None), (p["wi0"], (E, F), 1 / math.sqrt(E)), (p["wi1"], (E, F), 1 / math.sqrt(E)),
+                                                     (p["wo"], (F, E), 1 / math.sqrt(F))]
+  spec.append(("params/decoder/decoder_norm/scale", (E,), None))
+  if not getattr(cfg, "logits_via_embedding", False):
+    spec.append(("params/decoder/logits_dense/kernel", (E, V), 1 / math.sqrt(E)))
+  return spec
+
+
+def device_tree(cfg, seed: int = 0) -> DeviceTree:
+  return DeviceTree(device_tree_spec(cfg), seed)

@@ -27,49 +27,8 @@ synth = importlib.import_module("maxtext-indextts2_amd.synth")
 BASE = os.path.join(pyconfig.PKG_DIR, "configs", "base.yml")
 
 
-class DeviceTree:
-  """{MaxText tree path: bf16 CUDA tensor}, each tensor drawn when load_params asks for it and dropped afterwards."""
-
-  def __init__(self, spec, seed=0):
-    self.spec, self.seed = spec, seed
-
-  def items(self):
-    g = torch.Generator(device="cuda")
-    for i, (name, shape, std) in enumerate(self.spec):
-      g.manual_seed(self.seed * 100003 + i)
-      if std is None:
-        yield name, torch.ones(shape, dtype=torch.bfloat16, device="cuda")
-      else:
-        t = torch.empty(shape, dtype=torch.float32, device="cuda").normal_(0.0, std, generator=g).clamp_(-2 * std, 2 * std)
-        yield name, t.to(torch.bfloat16)
-        del t
-
-
-def gemma2_spec(cfg):
-  E, Q, KV, D, F, V = cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size
-  spec = [("params/token_embedder/embedding", (V, E), 1.0)]
-  for i in range(cfg.num_decoder_layers):
-    for sub in ("local", "global"):
-      p = synth.gemma2_layer_paths(i, sub)
-      spec += [(p["ln1"], (E,), None), (p["q"], (E, Q, D), 1 / math.sqrt(E * D)), (p["k"], (E, KV, D), 1 / math.sqrt(E)), (p["v"], (E, KV, D), 1 / math.sqrt(E)),
-               (p["o"], (Q, D, E), 1 / math.sqrt(Q * D)), (p["pan"], (E,), None), (p["ln2"], (E,), None), (p["wi0"], (E, F), 1 / math.sqrt(E)),
-               (p["wi1"], (E, F), 1 / math.sqrt(E)), (p["wo"], (F, E), 1 / math.sqrt(F)), (p["pfn"], (E,), None)]
-  spec.append(("params/decoder/decoder_norm/scale", (E,), None))
-  return spec
-
-
-def mixtral_spec(cfg):
-  E, Q, KV, D, F, V, NE = cfg.emb_dim, cfg.num_query_heads, cfg.num_kv_heads, cfg.head_dim, cfg.mlp_dim, cfg.vocab_size, cfg.num_experts
-  spec = [("params/token_embedder/embedding", (V, E), 1.0)]
-  for i in range(cfg.num_decoder_layers):
-    p = f"params/decoder/layers_{i}/"
-    spec += [(p + "pre_self_attention_layer_norm/scale", (E,), None), (p + "self_attention/query/kernel", (E, Q, D), 1 / math.sqrt(E * D)),
-             (p + "self_attention/key/kernel", (E, KV, D), 1 / math.sqrt(E)), (p + "self_attention/value/kernel", (E, KV, D), 1 / math.sqrt(E)),
-             (p + "self_attention/out/kernel", (Q, D, E), 1 / math.sqrt(Q * D)), (p + "post_self_attention_layer_norm/scale", (E,), None),
-             (p + "MoeBlock_0/gate/kernel", (E, NE), 4 / math.sqrt(E)), (p + "MoeBlock_0/wi_0", (NE, E, F), 1 / math.sqrt(E)),
-             (p + "MoeBlock_0/wi_1", (NE, E, F), 1 / math.sqrt(E)), (p + "MoeBlock_0/wo", (NE, F, E), 1 / math.sqrt(F))]
-  spec += [("params/decoder/decoder_norm/scale", (E,), None), ("params/decoder/logits_dense/kernel", (E, V), 1 / math.sqrt(E))]
-  return spec
+DeviceTree = synth.DeviceTree                      # weights drawn on the device, tensor by tensor (synth.py)
+gemma2_spec = mixtral_spec = synth.device_tree_spec
 
 
 def run(name, cfg, spec, prompt_len, chunk, slots, steps):
