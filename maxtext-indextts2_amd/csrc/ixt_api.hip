@@ -1100,6 +1100,20 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
 
+// decoders.py:552-565 on nl rows of f32 logits in place (/ sqrt(emb), soft cap), then the greedy choice over the allowed columns of the
+// post-processed values (the cap is not strictly monotone after rounding, so the maximum is taken after it).
+static int launch_logits_post(ixt_ctx* c, float* lg, int nl, int normalize, float cap, int32_t* argmax_out, hipStream_t st) {
+  const int nblk = (c->V + IXT_LPOST_COLS - 1) / IXT_LPOST_COLS;
+  if ((size_t)nl * nblk > c->amax_cap) return set_err(IXT_ERR_INVALID, "argmax workspace too small");
+  hipLaunchKernelGGL(k_logits_post, dim3(nblk, nl), dim3(256), 0, st, lg, c->V, normalize, sqrtf((float)c->E), cap, c->sample_cols, c->amax_val, c->amax_idx);
+  LAUNCHCHK();
+  if (argmax_out != nullptr) {
+    hipLaunchKernelGGL(k_argmax_final, dim3(nl), dim3(256), 0, st, c->amax_val, c->amax_idx, nblk, argmax_out);
+    LAUNCHCHK();
+  }
+  return IXT_OK;
+}
+
 // The Gemma-2 block over R rows (layers/gemma2.py:69-236): per (attention, MLP) sub-layer
 //   QKV dot -> k_qkv_finalize (RoPE, q -> qbuf, K/V -> pages) -> scores / softmax + PV (soft cap; sliding window on the even, "local"
 //   sub-layers) / combine -> O dot -> k_gnorm (post norm, residual, pre-MLP norm) -> wi dot -> GELU gate -> down dot -> k_gnorm (post norm,
@@ -1163,10 +1177,7 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
     // decoders.py:552-565: the division and the cap belong to the tied head
     const int normalize = cf.logits_via_embedding && cf.normalize_embedding_logits;
     const float cap = cf.logits_via_embedding ? cf.final_logits_soft_cap : 0.0f;
-    if (normalize || cap > 0.0f) {
-      hipLaunchKernelGGL(k_logits_post, dim3(nl), dim3(256), 0, st, lg, c->V, normalize, sqrtf((float)E), cap, c->sample_cols, argmax_out);
-      LAUNCHCHK();
-    }
+    if (normalize || cap > 0.0f) TRY(launch_logits_post(c, lg, nl, normalize, cap, argmax_out, st));
   }
   c->h_final = hcur; c->h_final_rows = R;
   return IXT_OK;
@@ -1274,7 +1285,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       // output does not depend on which other rows share its launch, so this equals the routed (permute / gmm / unpermute) form bit for
       // bit; it reads each expert's kernels once per pass, which is what decode with >= ~16 rows needs anyway, and spends
       // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
-      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
+      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(256), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
       LAUNCHCHK();
       for (int e = 0; e < c->NE; ++e) {
         TRY(launch_dot(c, c->xn, w.ewi[e], E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
@@ -1349,10 +1360,7 @@ extern "C" int ixt_prefill_prompt_logp(ixt_ctx* c, const int32_t* tokens_dev, in
     if (c->gemma) {   // decoders.py:552-565
       const int normalize = cf.logits_via_embedding && cf.normalize_embedding_logits;
       const float cap = cf.logits_via_embedding ? cf.final_logits_soft_cap : 0.0f;
-      if (normalize || cap > 0.0f) {
-        hipLaunchKernelGGL(k_logits_post, dim3(g), dim3(256), 0, st, c->plogits, c->V, normalize, sqrtf((float)c->E), cap, c->sample_cols, c->pargmax);
-        LAUNCHCHK();
-      }
+      if (normalize || cap > 0.0f) TRY(launch_logits_post(c, c->plogits, g, normalize, cap, c->pargmax, st));
     }
     TRY(ixt_op_logprob(c, c->plogits, g, tokens_dev + row0, prompt_logp_dev + row0, stream));
   }
@@ -1498,7 +1506,7 @@ extern "C" int ixt_op_moe_route(ixt_ctx* c, int layer, const uint16_t* x, int R,
   if (!x || !experts_out || !weights_out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   TRY(transpose_rows(c, x, R, c->E, st));
-  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
+  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(256), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
   LAUNCHCHK();
   return IXT_OK;
 }

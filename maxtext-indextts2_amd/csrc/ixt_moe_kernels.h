@@ -9,13 +9,13 @@
 #define IXT_MOE_MAX_EXPERTS 32
 #define IXT_MOE_MAX_TOPK 8
 
-// grid = R, block = 64.  xn: the dot kernels' x layout (xidx); gate: row-major bf16 [E][n_exp].
-__global__ __launch_bounds__(64) void k_moe_route(const bf16_t* xn, const bf16_t* gate, int E, int n_exp, int top_k, int32_t* idx_out /*[R][top_k]*/,
+// grid = R, block = 256 (4 waves, each takes every fourth expert's logit).  xn: the dot kernels' x layout (xidx); gate: row-major bf16 [E][n_exp].
+__global__ __launch_bounds__(256) void k_moe_route(const bf16_t* xn, const bf16_t* gate, int E, int n_exp, int top_k, int32_t* idx_out /*[R][top_k]*/,
                                                   float* w_out /*[R][top_k]*/) {
   __shared__ float gl[IXT_MOE_MAX_EXPERTS];
-  const int r = blockIdx.x, lane = threadIdx.x;
+  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = E / 8, nblk = (nch + 63) / 64;
-  for (int e = 0; e < n_exp; ++e) {
+  for (int e = wave; e < n_exp; e += 4) {
     float total = 0.0f;
     for (int b = 0; b < nblk; ++b) {
       const int ch = b * 64 + lane;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void k_moe_route(const bf16_t* xn, const bf16_t
     if (lane == 0) gl[e] = rbf(total);
   }
   __syncthreads();
-  if (lane != 0) return;
+  if (threadIdx.x != 0) return;
   float v[IXT_MOE_MAX_TOPK], ex[IXT_MOE_MAX_TOPK];
   uint32_t taken = 0;
   for (int j = 0; j < top_k; ++j) {
