@@ -5,11 +5,18 @@ configs[1], "C2"), data-parallel over N GPUs of one node (one process per GPU, n
   python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts N rank processes itself, before any GPU call)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 1024, the engine's maximum) utterances per GPU,
-each a 256-token prompt (4 s reference speech + 128-char text) prefilled -- `--prefill-pack` (default 16)
+A "step" is one pass of the hot path over one batch of synthetic input: `--batch` (default 256) utterances per GPU,
+each a 256-token prompt (4 s reference speech + 128-char text) prefilled -- `--prefill-pack` (default 8)
 prompts per pass over the weights through the engine's prefill_concat / insert_partial (maxengine.py:719-836, 1206-1318) -- then
-`--decode-steps` (default 1024) greedy generate calls for all slots.  Tokens counted = generated audio tokens
+`--decode-steps` (default 1024) greedy generate calls for all slots, then ONE fetch of all generated ids to the host (decode.py:162-184
+reads them; SURVEY.md section 8e "results gathered on host as int32 ids").  Tokens counted = generated audio tokens
 including the first one from prefill (decode.py:162-178: T-P generate calls yield T-P+1 tokens per utterance).
+Protocol = the reference's micro-benchmark (inference_microbenchmark.py:149-197): warm-up passes, then a timed loop closed by a device sync.
+
+The driver's command is `python3 bench.py --gpus 1 --steps 20 --warmup 5` under a 600 s limit: 25 passes of the default batch take about
+175 s.  Everything after the timed region runs against a wall-clock budget (`--budget-s`, counted from process start): `roofline` and
+`cpu_baseline` always, the extra rows under `detail` (one / eight utterances, the 4096-token chunked prefill, one pass each at 512 and 1024
+utterances per GPU) only while the budget allows; rows left out are named in `detail.skipped`.
 Rank 0 prints ONE JSON line.
 """
 from __future__ import annotations
@@ -42,18 +49,23 @@ def parse(argv=None):
   ap.add_argument("--gpus", type=int, default=1)
   ap.add_argument("--steps", type=int, default=2)
   ap.add_argument("--warmup", type=int, default=1)
-  ap.add_argument("--batch", type=int, default=1024, help="utterances (decode slots) per GPU; 1024 (172 GB of paged K/V at 1280 tokens each) is the engine's maximum")
+  ap.add_argument("--batch", type=int, default=256, help="utterances (decode slots) per GPU; 1024 (172 GB of paged K/V at 1280 tokens each) is the engine's maximum")
+  ap.add_argument("--budget-s", type=float, default=420.0, help="wall-clock budget of the whole process; optional detail rows are skipped once it would be exceeded")
+  ap.add_argument("--big-rows", default="1024,512", help="utterances per GPU of the extra one-pass rows under detail.big_batch_rows (budget permitting)")
   ap.add_argument("--decode-steps", type=int, default=1024)
   ap.add_argument("--prefill-len", type=int, default=256)
-  ap.add_argument("--prefill-pack", type=int, default=16, help="prompts per packed prefill (prefill_concat); 1 = one prefill call per utterance")
+  ap.add_argument("--prefill-pack", type=int, default=8, help="prompts per packed prefill (prefill_concat); 1 = one prefill call per utterance")
   ap.add_argument("--model", default="indextts2-1b")
   ap.add_argument("--no-graph", action="store_true")
   ap.add_argument("--no-cpu-baseline", action="store_true")
   ap.add_argument("--no-roofline", action="store_true")
   ap.add_argument("--no-batch-rows", action="store_true", help="skip the B=1 / B=8 rows of SURVEY.md section 8(d)")
-  ap.add_argument("--no-detail", action="store_true", help="skip the separate prefill-only / decode-only pass (profiling runs)")
+  ap.add_argument("--no-detail", action="store_true", help="no prefill / decode split events inside the timed passes (profiling runs)")
+  ap.add_argument("--no-big-rows", action="store_true", help="skip the one-pass rows at larger batches")
+  ap.add_argument("--no-fetch", action="store_true", help="do not fetch the generated ids to the host at the end of a pass (counter runs)")
   ap.add_argument("--cpu-batch", type=int, default=16, help="utterances of the CPU baseline sample")
   ap.add_argument("--cpu-slice-steps", type=int, default=2)
+  ap.add_argument("--cpu-check-steps", type=int, default=4, help="decode steps of utterance 0 the parity oracle replays to check the fetched ids")
   ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the CPU baseline (the GPU box's CPU share for one GPU is 16)")
   ap.add_argument("--sync-every", type=int, default=0, help="synchronise the stream every N engine calls (profiling runs: bounds the launch backlog)")
   ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for the CPU rehearsal)")
@@ -104,10 +116,13 @@ def gpu_weights(cfg, device, seed=0):
 class Workload:
   """One GPU's share: B utterances through the engine's own prefill / insert / generate surface."""
 
-  def __init__(self, eng, params, prompts_dev, decode_steps, pack, sync_every=0, sync=None):
+  def __init__(self, eng, params, prompts_dev, decode_steps, pack, sync_every=0, sync=None, fetch=True, split_events=False):
     self.eng, self.params, self.prompts, self.decode_steps = eng, params, prompts_dev, decode_steps
     self.pack, self.sync_every, self.sync, self.calls = max(1, pack), sync_every, sync, 0
     self._packed = None
+    self.fetch, self.split_events = fetch, split_events
+    self.last_ids = None        # host int32 [B, decode_steps + 1] of the last pass (first token from prefill, then one per generate call)
+    self.splits = []            # per pass (start, prefill done, decode done) events on the launch stream
 
   def _tick(self):
     self.calls += 1
@@ -159,10 +174,38 @@ class Workload:
     for s in range(len(self.prompts)):
       self.eng.release_pages(s)
 
+  def _event(self):
+    import torch
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record(torch.cuda.current_stream())     # the engine launches on torch's current stream (maxengine._stream_ptr)
+    return ev
+
   def one_pass(self):
+    """Prefill every utterance, decode, hand the ids to the host in ONE copy at the end (the only host synchronisation of a pass)."""
+    ev = [self._event()] if self.split_events else None
     ds = self.prefill_all(self.eng.init_decode_state())
-    self.decode_all(ds)
+    if ev:
+      ev.append(self._event())
+    collect = None
+    if self.fetch:
+      collect = [ds["tokens"].clone()]           # [B, 1] first tokens (from prefill), in slot order
+    self.decode_all(ds, collect=collect)
+    if ev:
+      ev.append(self._event())
+      self.splits.append(ev)
+    if self.fetch:
+      import torch
+      self.last_ids = torch.cat([collect[0]] + [c[:, 0:1] for c in collect[1:]], dim=1).cpu()
     self.release_all()
+
+  def split_ms(self, last_n):
+    """(prefill ms, decode ms) means over the last `last_n` passes, from the events recorded inside them."""
+    rows = self.splits[-last_n:]
+    if not rows:
+      return None
+    pre = sum(a.elapsed_time(b) for a, b, _ in rows) / len(rows)
+    dec = sum(b.elapsed_time(c) for _, b, c in rows) / len(rows)
+    return pre, dec
 
 
 class _StubEngine:
@@ -242,7 +285,8 @@ def run_rank(args):
     # distinct utterances per rank and slot: seeds 1234 + global utterance index
     prompts = [synth.synth_prompt(cfg.vocab_size, P, 1234 + rank * B + s) for s in range(B)]
     prompts_dev = [(torch.from_numpy(t).to(device), tl) for t, tl in prompts]
-  wl = Workload(eng, params, prompts_dev, args.decode_steps, pack, args.sync_every, sync_dev)
+  wl = Workload(eng, params, prompts_dev, args.decode_steps, pack, args.sync_every, sync_dev, fetch=not args.no_fetch,
+                split_events=not (stub or args.no_detail))
 
   _log(f"rank {rank}: engine and weights ready")
   # ---- the timed region: W warm-up passes, then exactly K passes between barriers; MAX over ranks (dp.timed_region)
@@ -267,37 +311,62 @@ def run_rank(args):
 
   nums = model_numbers(cfg)
   if rank == 0:
-    out["detail"] = {} if args.no_detail else detail_split(args, wl, eng, nums, B, P)
-    _log("prefill / decode split done")
+    budget = Budget(args.budget_s)
+    out["detail"] = {"skipped": budget.skipped, "budget_s": args.budget_s}
+    sp = wl.split_ms(args.steps)
+    if sp:
+      out["detail"].update(detail_split(args, nums, B, P, sp[0] * 1e-3, sp[1] * 1e-3))
+    gpu_ids = wl.last_ids
     out["roofline"] = None if args.no_roofline else roofline(args, wl, eng, cfg, nums, prompts, B)
     _log("live roofline done")
+    out["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(args, cfg, weights, prompts, gpu_ids)
+    _log("cpu baseline done")
+    del wl, eng, params                    # the rows below build their own engines: give the page pool back first
+    torch.cuda.empty_cache()
     if not args.no_batch_rows:
-      _log("long-prompt chunked prefill row")
-      out["detail"]["long_prefill"] = long_prefill_row(args, weights, nums)
-      out["detail"]["long_prefill_chunk1024"] = long_prefill_row(args, weights, nums, chunk=1024)
       out["detail"]["batch_rows"] = []
       for b in (1, 8):
-        out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
-        _log(f"batch row B={b} done")
-    out["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(args, cfg, weights, prompts)
-    _log("cpu baseline done")
+        if budget.allows(f"batch_rows[{b}]", 12.0 + 3.2 * args.decode_steps / 1024):
+          out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
+          _log(f"batch row B={b} done")
+      for key, chunk in (("long_prefill", None), ("long_prefill_chunk1024", 1024)):
+        if budget.allows(key, 8.0):
+          out["detail"][key] = long_prefill_row(args, weights, nums, chunk=chunk)
+          _log(f"{key} done")
+    if not args.no_big_rows:
+      out["detail"]["big_batch_rows"] = []
+      for b in [int(v) for v in args.big_rows.split(",") if v]:
+        if b == B:
+          continue
+        # one pass at b utterances: decode time grows a little faster than linearly below the attention-bound range; 1.5x margin + set-up
+        est = 15.0 + 1.5 * (out["ms_per_step"] * 1e-3) * b / B
+        if budget.allows(f"big_batch_rows[{b}]", est):
+          out["detail"]["big_batch_rows"].append(big_row(args, b, weights, cfg, nums, rank))
+          _log(f"big batch row B={b} done")
+    out["wall_s"] = time.time() - _T0
     print(json.dumps(out), flush=True)
   dp.finish()
 
 
-def detail_split(args, wl, eng, nums, B, P):
-  """Prefill-only and decode-only times of one more pass (rank 0 reporting detail)."""
-  import torch
-  torch.cuda.synchronize()
-  t1 = time.perf_counter()
-  ds = wl.prefill_all(eng.init_decode_state())
-  torch.cuda.synchronize()
-  t_prefill = time.perf_counter() - t1
-  t2 = time.perf_counter()
-  wl.decode_all(ds)
-  torch.cuda.synchronize()
-  t_decode = time.perf_counter() - t2
-  wl.release_all()
+class Budget:
+  """Wall-clock budget of the optional rows: a row runs only if its estimated cost still fits; what was left out is listed in the JSON."""
+
+  def __init__(self, total_s):
+    self.total, self.skipped = total_s, []
+
+  def left(self):
+    return self.total - (time.time() - _T0)
+
+  def allows(self, name, estimate_s):
+    if self.left() >= estimate_s:
+      return True
+    self.skipped.append({"row": name, "estimate_s": round(estimate_s, 1), "left_s": round(self.left(), 1)})
+    _log(f"skipping {name}: needs ~{estimate_s:.0f} s, {self.left():.0f} s of the budget left")
+    return False
+
+
+def detail_split(args, nums, B, P, t_prefill, t_decode):
+  """Prefill / decode split of the TIMED passes (means of the events recorded inside them on the launch stream)."""
   ms_step = t_decode / args.decode_steps * 1e3
   mean_ctx = P + args.decode_steps / 2.0
   step_bytes = (nums["body_params"] + nums["unembed_params"]) * 2 + B * mean_ctx * nums["kv_bytes_per_token"] + B * nums["kv_bytes_per_token"]
@@ -306,7 +375,36 @@ def detail_split(args, wl, eng, nums, B, P):
   return {"prefill_ms_per_utterance": t_prefill / B * 1e3, "prefill_mfu": prefill_flops / (t_prefill / B) / MFMA_BF16_PEAK,
           "decode_ms_per_step": ms_step, "decode_tokens_per_s": B / (ms_step * 1e-3),
           "decode_step_algorithmic_bytes": step_bytes, "decode_hbm_frac": step_bytes / (ms_step * 1e-3) / HBM_PEAK,
-          "decode_mfu": step_flops / (ms_step * 1e-3) / MFMA_BF16_PEAK}
+          "decode_mfu": step_flops / (ms_step * 1e-3) / MFMA_BF16_PEAK, "source": "HIP events inside the timed passes"}
+
+
+def big_row(args, b, weights, cfg0, nums, rank):
+  """ONE full pass (after a short warm-up that captures the step graph) at `b` utterances per GPU: the same workload at a larger batch,
+  where the decode attention reaches the read ceiling of its access pattern.  Reported beside the headline, never as `value`."""
+  import torch
+  pyconfig = importlib.import_module("maxtext-indextts2_amd.pyconfig")
+  maxengine = importlib.import_module("maxtext-indextts2_amd.maxengine")
+  synth = importlib.import_module("maxtext-indextts2_amd.synth")
+  sub = argparse.Namespace(**vars(args))
+  sub.prefill_pack = 16
+  cfg, eng, pack = make_engine(sub, pyconfig, maxengine, b)
+  params = eng.load_params(params=weights)
+  dev = eng.device
+  prompts_dev = [(torch.from_numpy(t).to(dev), tl) for t, tl in (synth.synth_prompt(cfg.vocab_size, args.prefill_len, 1234 + rank * b + s) for s in range(b))]
+  wl = Workload(eng, params, prompts_dev, args.decode_steps, pack, split_events=True)
+  ds = wl.prefill_all(eng.init_decode_state())          # warm-up: every packed prefill once, 8 decode steps (graph capture), release
+  wl.decode_all(ds, steps=8)
+  wl.release_all()
+  torch.cuda.synchronize()
+  t0 = time.perf_counter()
+  wl.one_pass()
+  torch.cuda.synchronize()
+  dt = time.perf_counter() - t0
+  pre_ms, dec_ms = wl.split_ms(1)
+  del wl, eng
+  torch.cuda.empty_cache()
+  return {"utterances": b, "prefill_pack": pack, "passes": 1, "seconds_per_pass": dt, "tokens_per_s": b * (args.decode_steps + 1) / dt,
+          "prefill_ms_per_utterance": pre_ms / b, "decode_ms_per_step": dec_ms / args.decode_steps}
 
 
 def roofline(args, wl, eng, cfg, nums, prompts, B):
@@ -339,17 +437,21 @@ def roofline(args, wl, eng, cfg, nums, prompts, B):
   att_bpl = ctx_sum * kv_layer + B * kv_layer                                    # read every cached key/value once + the new one
   build_id = lib.ixt_build_id().decode()
   traffic, traffic_src, mfma, stale = None, None, None, None
-  pmc = os.path.join(ROOT, "profiles", "r02_pmc.json")
-  if os.path.exists(pmc):
+  import glob
+  for pmc in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc*.json")), reverse=True):      # newest round first
     try:
       pj = json.load(open(pmc))
-      if pj.get("batch") == B and pj.get("model") == args.model:
-        if pj.get("build_id") == build_id:      # counters of THIS build only
-          traffic, traffic_src, mfma = pj.get("attn_hbm_bytes_per_launch"), pj.get("source"), pj.get("mfma")
-        else:
-          stale = f"profiles/r02_pmc.json was measured on build {pj.get('build_id')}, this is {build_id}"
     except Exception:  # pylint: disable=broad-except
-      pass
+      continue
+    if pj.get("batch") != B or pj.get("model") != args.model:
+      continue
+    if pj.get("build_id") == build_id:      # counters of THIS build only
+      traffic, mfma = pj.get("attn_hbm_bytes_per_launch"), pj.get("mfma")
+      traffic_src = (f"{os.path.relpath(pmc, ROOT)} -- NOT this run: separate rocprofv3 --pmc passes of the same build on the workload "
+                     f"'{pj.get('workload', pj.get('source'))}'; " + str(pj.get("source")))
+      stale = None
+      break
+    stale = stale or f"{os.path.relpath(pmc, ROOT)} was measured on build {pj.get('build_id')}, this is {build_id}"
   dot = {"kernel": "k_gemm_ring / k_gemm / k_dotb / k_unembed (canonical dot on v_mfma_f32_16x16x32_bf16), all launches of a decode step", "bound": "hbm",
          "achieved": dot_bpl / (dot_us * 1e-6) / 1e9 if dot_us > 0 else 0.0, "unit": "GB/s", "avg_launch_us": dot_us, "launches": dot_n,
          "algorithmic_bytes_per_launch": dot_bpl, "us_per_step": dot_us * dot_n / nmeas}
@@ -436,10 +538,12 @@ def long_prefill_row(args, weights, nums, total=4096, chunk=None):
   return {"prompt_tokens": total, "chunk": P, "seconds": dt, "prefill_tokens_per_s": total / dt, "mfu": flops / dt / MFMA_BF16_PEAK}
 
 
-def cpu_baseline(args, cfg, weights, prompts):
+def cpu_baseline(args, cfg, weights, prompts, gpu_ids=None):
   """The reference ALGORITHM on this host's CPU cores (oracle/ref_algo_cpu.py: dense two-segment cache, both full buffers read at every step,
   [1, P, V] prefill logits, bf16 values / f32 accumulation), on a bounded sample of the workload.  JAX (the north star's `jax.devices('cpu')`)
-  is not installed anywhere in this pipeline; this torch-CPU restatement is the labelled stand-in of BASELINE.md section 3."""
+  is not installed anywhere in this pipeline; this torch-CPU restatement is the labelled stand-in of BASELINE.md section 3.
+  `gpu_ids` (the ids the last timed pass fetched) are CHECKED here against the parity oracle (oracle/ixt_oracle.c: utterance 0, the first
+  1 + `--cpu-check-steps` ids, bit-exact contract) and against the independent f32 restatement's first token."""
   import numpy as np
   import torch
   from oracle import ref_algo_cpu as RA
@@ -454,10 +558,32 @@ def cpu_baseline(args, cfg, weights, prompts):
     model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo", encoding="utf-8") if l.startswith("model name")][0]
   except Exception:  # pylint: disable=broad-except
     pass
-  r.update({"host_cpus": os.cpu_count(), "cpu_model": model,
+  r.update({"kind": "port", "host_cpus": os.cpu_count(), "cpu_model": model,
             "sample": f"torch-cpu restatement of the reference algorithm (JAX unavailable), {r['matmul']} matmul, {r['cores']} threads: {cb} utterances, one "
                       f"{args.prefill_len}-token prefill timed ({r['prefill_s_per_utterance']:.2f} s, charged {cb} times) + {args.cpu_slice_steps}-step decode slices at "
                       f"three ring positions ({', '.join(f'{s:.3f}' for s in r['decode_slices_s_per_step'])} s/step), integrated over {args.decode_steps} steps"})
+  if gpu_ids is not None:
+    n = max(0, min(args.cpu_check_steps, args.decode_steps))
+    from oracle import oracle as O
+    O.lib().orc_set_num_threads(threads)
+    T = args.prefill_len + args.decode_steps
+    ocfg = O.OracleConfig(vocab_size=cfg.vocab_size, emb_dim=cfg.emb_dim, num_query_heads=cfg.num_query_heads, num_kv_heads=cfg.num_kv_heads,
+                          head_dim=cfg.head_dim, mlp_dim=cfg.mlp_dim, num_decoder_layers=cfg.num_decoder_layers,
+                          normalization_layer_epsilon=cfg.normalization_layer_epsilon, max_target_length=T, max_prefill_predict_length=args.prefill_len,
+                          pagedattn_num_pages=(T + 31) // 32 + 1, pagedattn_tokens_per_page=32, max_slots=1)
+    orc = O.OracleEngine(O.OracleModel(ocfg, host_w))
+    toks, tl = prompts[0]
+    opre, ores = orc.prefill(toks, tl, slot=0)
+    ods = orc.insert(opre, orc.init_decode_state(), 0)
+    otoks = [int(ores[0, 0])]
+    for _ in range(n):
+      ods, orr = orc.generate(ods)
+      otoks.append(int(orr[0, 0]))
+    gtoks = [int(v) for v in gpu_ids[0, :n + 1]]
+    r.update({"tokens_match_gpu": otoks == gtoks, "tokens_compared": n + 1,
+              "tokens_checker": "oracle/ixt_oracle.c (parity oracle, bit-exact contract) on utterance 0 against the ids the last timed pass fetched",
+              "ref_algo_first_token_matches_gpu": int(r["first_token"]) == gtoks[0]})
+    _log(f"token check: oracle {otoks} gpu {gtoks}")
   return r
 
 

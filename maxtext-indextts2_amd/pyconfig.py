@@ -6,7 +6,10 @@ Behaviour mirrored from /root/reference/MaxText/pyconfig.py for the hot-path key
   * every CLI / kwarg / env key must already exist in the yaml                           (:437-439)
   * env override `M_<KEY>`; CLI + env for one key is an error                            (:48-49, :414-421, :441-443)
   * a value given as text is parsed to the type of the yaml default                      (:462-471)
-  * `model_name` pulls configs/models/<name>.yml, explicit overrides win                 (:682-703)
+  * `model_name` pulls configs/models/<name>.yml; a key set both there and at the CLI /
+    environment is an error unless `override_model_config` is true (then the CLI wins)   (:368-374, :510-511, :682-703)
+  * `validate_and_update_keys`: a model key must exist with the same type; the
+    `logical_axis_rules` list is merged rule by rule                                     (:990-1041)
   * derived keys (emb_dim, num_query_heads, ..., global_batch_size_to_load,
     pagedattn_max_pages_per_group)                                                       (:551-644, :1044-1086)
   * the result is read-only                                                              (:1163-1164)
@@ -97,6 +100,31 @@ def _as_type_of(default: Any, proposal: Any, key: str) -> Any:
   raise ValueError(f"For key '{key}', type {type(default)} not in [str, int, float, bool], can't pass at the CLI or ENV")
 
 
+# ------------------------------------------------------------------------------------------------ model keys
+def _freeze(x):
+  return tuple(_freeze(v) for v in x) if isinstance(x, list) else x
+
+
+def create_new_logical_axis_rules(old_logical_axis_rules, new_logical_axis_rules):
+  """pyconfig.py:1001-1016: rules of the model file replace the rules of the same logical axis (moved to the end, mesh axes as given);
+  untouched rules keep their place with their mesh axes frozen to tuples; a rule for an axis the base does not know is dropped."""
+  known = {rule[0] for rule in old_logical_axis_rules}
+  taken = [(axis, mesh) for axis, mesh in new_logical_axis_rules if axis in known]
+  replaced = {axis for axis, _ in taken}
+  return [(axis, _freeze(mesh)) for axis, mesh in old_logical_axis_rules if axis not in replaced] + taken
+
+
+def validate_and_update_keys(raw_keys, model_keys, config_name: str):
+  """pyconfig.py:1019-1041: every key of a model file must exist in the config with a value of the same type; then it replaces it."""
+  for key, value in model_keys.items():
+    if key not in raw_keys:
+      raise ValueError(f"Key {key} does not exist in config {config_name}.")
+    if not isinstance(raw_keys[key], type(value)):
+      raise ValueError(f"Type of key:{key} does not match with {type(value)}")
+    raw_keys[key] = create_new_logical_axis_rules(raw_keys[key], value) if key == "logical_axis_rules" else value
+  return raw_keys
+
+
 # ------------------------------------------------------------------------------------------------ derived keys
 def get_individual_scales(scale):
   """pyconfig.py:1044-1064: a power-of-two parameter scale spread over (emb, heads, mlp, layers), three doublings per round:
@@ -159,16 +187,21 @@ def _resolve(argv: List[str], kwargs: Mapping[str, Any]) -> Dict[str, Any]:
   overrides = _collect_overrides(list(argv[2:]), kwargs, defaults)
   keys = {k: (_as_type_of(d, overrides[k][0], k) if k in overrides else d) for k, d in defaults.items()}
   name = keys["model_name"]
-  if name != "default":                                     # the model file fills what nobody set explicitly (pyconfig.py:682-703)
-    path = os.path.join(PKG_DIR, "configs", "models", f"{name}.yml")
+  if name != "default":                                     # pyconfig.py:682-703
+    path = os.path.join(os.path.dirname(os.path.abspath(argv[1])), "models", f"{name}.yml")
+    if not os.path.isfile(path):
+      path = os.path.join(PKG_DIR, "configs", "models", f"{name}.yml")
     if not os.path.isfile(path):
       raise ValueError(f"Invalid model name {name}: no {path}")
     with open(path, "r", encoding="utf-8") as f:
-      for k, v in (yaml.safe_load(f) or {}).items():
-        if k not in defaults:
-          raise ValueError(f"Key {k} in model config {name} isn't in config.")
-        if k not in overrides:
-          keys[k] = v
+      model_keys = yaml.safe_load(f) or {}
+    if keys["override_model_config"]:                       # debugging / testing: what was given explicitly wins over the model file
+      model_keys = {k: v for k, v in model_keys.items() if k not in overrides}
+    else:
+      twice = [k for k in overrides if k in model_keys]
+      if twice:
+        raise ValueError(f"Keys {twice} are overwritten from both the model and the environment/command line. This isn't allowed.")
+    validate_and_update_keys(keys, model_keys, config_name=argv[1])
   _derive(keys)
   return keys
 

@@ -59,7 +59,8 @@ class RefAlgoCPU:
           "wout": cv(p + "mlp/wo/kernel", (self.F, self.E)),
       })
     half = self.D // 2
-    ts = (1.0 * (10000.0 ** (torch.arange(half, dtype=torch.float32) * 2 / self.D)))
+    lo, hi = float(getattr(cfg, "rope_min_timescale", 1)), float(getattr(cfg, "rope_max_timescale", 10000))
+    ts = (lo * ((hi / lo) ** (torch.arange(half, dtype=torch.float32) * 2 / self.D)))       # embeddings.py:254-268
     ang = torch.arange(target_len, dtype=torch.float32)[:, None] / ts[None, :]
     self.sin, self.cos = torch.sin(ang).to(torch.bfloat16), torch.cos(ang).to(torch.bfloat16)
     A = target_len - prefill_len
@@ -125,6 +126,7 @@ class RefAlgoCPU:
       h = h + self._mlp(lw, self._norm(h, lw["ln2"]))
     logits = (self._norm(h, self.final_norm).to(self.wdt) @ self.logits_w).float()   # [1, P, V]: every row (maxengine.py:462-476)
     first = int(torch.argmax(logits[0, true_length - 1]))
+    self.last_logits = logits[0, true_length - 1:true_length].clone()               # [1, V] (tests/test_cross_oracle_cpu.py)
     self.pseg[slot] = seg
     self.aseg[slot] = 0
     self.next_pos[slot], self.tokens[slot] = true_length, first
@@ -153,6 +155,7 @@ class RefAlgoCPU:
       h = h + self._mlp(lw, self._norm(h, lw["ln2"]))
     logits = (self._norm(h, self.final_norm).to(self.wdt) @ self.logits_w).float()   # [B, 1, V]
     new = torch.argmax(logits[:, 0], dim=-1)
+    self.last_logits = logits[:, 0]                                                 # [B, V]
     self.tokens, self.next_pos = new, self.next_pos + 1
     self.ar_index = (idx + 1) % A                                                   # kvcache.py:778
     return new.numpy()

@@ -133,3 +133,52 @@ class TrainOracle:
     total_loss = total_loss.detach()
     return {"learning/loss": float(total_loss) / denom, "learning/total_weights": float(total_weights), "learning/raw_grad_norm": raw,
             "learning/grad_norm": raw * f, "learning/current_learning_rate": lr, "grads": grads}
+
+
+# ---- stand-alone restatements pinned by the reference's own test cases (tests/test_reference_cases_cpu.py)
+def cross_entropy_with_logits(logits: np.ndarray, targets_one_hot: np.ndarray, z_loss: float = 0.0):
+  """max_utils.py:563-621 (the forward rule of the custom VJP, :594-621): (loss, z_loss term) per position, stabilised by the row maximum."""
+  logits = np.asarray(logits)
+  m = logits.max(axis=-1, keepdims=True)
+  shifted = logits - m
+  sum_exp = np.exp(shifted).sum(axis=-1, keepdims=True)
+  log_softmax = shifted - np.log(sum_exp)
+  loss = -(targets_one_hot * log_softmax).sum(axis=-1)
+  log_z = (np.log(sum_exp) + m)[..., 0]
+  total_z = z_loss * np.square(log_z)
+  return loss + total_z, total_z
+
+
+def cross_entropy_vjp(logits: np.ndarray, targets_one_hot: np.ndarray, z_loss: float, g: np.ndarray) -> np.ndarray:
+  """max_utils.py:624-651: d loss / d logits under the custom VJP = g * ((1 + 2 z log_z) softmax - targets)."""
+  m = logits.max(axis=-1, keepdims=True)
+  e = np.exp(logits - m)
+  s = e.sum(axis=-1, keepdims=True)
+  log_z = np.log(s) + m
+  return g[..., None] * ((1.0 + 2.0 * z_loss * log_z) * e / s - targets_one_hot)
+
+
+def l2norm_pytree(tree) -> float:
+  """max_utils.py:72-74: sqrt of the sum of squares over every leaf of a (nested dict / list) tree."""
+  if isinstance(tree, dict):
+    tree = list(tree.values())
+  if isinstance(tree, (list, tuple)):
+    return math.sqrt(sum(l2norm_pytree(t) ** 2 for t in tree))
+  return math.sqrt(float(np.sum(np.square(np.asarray(tree, np.float64)))))
+
+
+def apply_gradient_clipping(raw_grads: dict, clipping_threshold: float, keep_key: str = "_overwrite_with_gradient") -> dict:
+  """maxtext_utils.py:825-846 = optax.clip_by_global_norm over everything except the fp8 statistics subtree (`keep_key`), which neither
+  counts towards the norm nor is scaled: g * threshold / max(norm, threshold)."""
+  body = {k: v for k, v in raw_grads.items() if k != keep_key}
+  norm = l2norm_pytree(body)
+  f = clipping_threshold / max(norm, clipping_threshold)
+
+  def scale(t):
+    if isinstance(t, dict):
+      return {k: scale(v) for k, v in t.items()}
+    return np.asarray(t, np.float32) * np.float32(f)
+  out = scale(body)
+  if keep_key in raw_grads:
+    out[keep_key] = raw_grads[keep_key]
+  return out

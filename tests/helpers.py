@@ -20,7 +20,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 def make_config(model_name="ixt-tiny", **overrides):
   kw = dict(model_name=model_name, attention="paged", scan_layers=False, per_device_batch_size=1.0,
             max_prefill_predict_length=32, max_target_length=128, pagedattn_num_pages=64, pagedattn_tokens_per_page=8,
-            enable_checkpointing=False, run_name="test")
+            enable_checkpointing=False, run_name="test",
+            override_model_config=True)     # the tests resize the named models (base.yml:20: the reference's switch for exactly that)
   kw.update(overrides)
   return pyconfig.initialize(["test", BASE_YML], **kw)
 

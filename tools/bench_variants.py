@@ -84,7 +84,7 @@ def main():
   ap.add_argument("--layers", type=int, default=0, help="override base_num_decoder_layers (0: the model file's)")
   ap.add_argument("--steps", type=int, default=64)
   args = ap.parse_args()
-  common = dict(attention="paged", scan_layers=False, pagedattn_tokens_per_page=32, run_name="bench_variants", use_chunked_prefill=True)
+  common = dict(attention="paged", scan_layers=False, pagedattn_tokens_per_page=32, run_name="bench_variants", use_chunked_prefill=True, override_model_config=True)
   if "gemma2" in args.which:
     kw = dict(base_num_decoder_layers=args.layers) if args.layers else {}
     cfg = pyconfig.initialize(["bench", BASE], model_name="gemma2-2b", vocab_size=256128 + 2048, per_device_batch_size=8.0, max_prefill_predict_length=256,
