@@ -317,22 +317,43 @@ def run_rank(args):
     if sp:
       out["detail"].update(detail_split(args, nums, B, P, sp[0] * 1e-3, sp[1] * 1e-3))
     gpu_ids = wl.last_ids
-    out["roofline"] = None if args.no_roofline else roofline(args, wl, eng, cfg, nums, prompts, B)
-    _log("live roofline done")
-    out["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else cpu_baseline(args, cfg, weights, prompts, gpu_ids)
-    _log("cpu baseline done")
-    del wl, eng, params                    # the rows below build their own engines: give the page pool back first
+    def guarded(name, fn):
+      """roofline / cpu_baseline: an exception becomes {"error": ...} under the key -- the headline line must print whatever happens here."""
+      try:
+        r = fn()
+        _log(f"{name} done")
+        return r
+      except Exception as ex:  # pylint: disable=broad-except
+        _log(f"{name} FAILED: {type(ex).__name__}: {ex}")
+        return {"error": f"{type(ex).__name__}: {ex}"[:300]}
+    out["roofline"] = None if args.no_roofline else guarded("live roofline", lambda: roofline(args, wl, eng, cfg, nums, prompts, B))
+    out["cpu_baseline"] = None if (world > 1 or args.no_cpu_baseline) else guarded("cpu baseline", lambda: cpu_baseline(args, cfg, weights, prompts, gpu_ids))
+    wl.eng = None
+    eng.close()                            # the rows below build their own engines: give the page pool back first
+    del wl, eng, params
     torch.cuda.empty_cache()
+
+    def optional(name, estimate_s, fn):
+      """One optional row: skipped when the budget does not cover its estimate; a failure is recorded, never raised (the line must print)."""
+      if not budget.allows(name, estimate_s):
+        return None
+      try:
+        r = fn()
+        _log(f"{name} done")
+        return r
+      except Exception as ex:  # pylint: disable=broad-except
+        budget.skipped.append({"row": name, "error": f"{type(ex).__name__}: {ex}"[:300]})
+        _log(f"{name} FAILED: {ex}")
+        torch.cuda.empty_cache()
+        return None
+
     if not args.no_batch_rows:
-      out["detail"]["batch_rows"] = []
-      for b in (1, 8):
-        if budget.allows(f"batch_rows[{b}]", 12.0 + 3.2 * args.decode_steps / 1024):
-          out["detail"]["batch_rows"].append(batch_row(args, b, weights, prompts_dev, nums))
-          _log(f"batch row B={b} done")
+      rows = [optional(f"batch_rows[{b}]", 12.0 + 3.2 * args.decode_steps / 1024, lambda b=b: batch_row(args, b, weights, prompts_dev, nums)) for b in (1, 8)]
+      out["detail"]["batch_rows"] = [r for r in rows if r is not None]
       for key, chunk in (("long_prefill", None), ("long_prefill_chunk1024", 1024)):
-        if budget.allows(key, 8.0):
-          out["detail"][key] = long_prefill_row(args, weights, nums, chunk=chunk)
-          _log(f"{key} done")
+        r = optional(key, 8.0, lambda chunk=chunk: long_prefill_row(args, weights, nums, chunk=chunk))
+        if r is not None:
+          out["detail"][key] = r
     if not args.no_big_rows:
       out["detail"]["big_batch_rows"] = []
       for b in [int(v) for v in args.big_rows.split(",") if v]:
@@ -340,9 +361,9 @@ def run_rank(args):
           continue
         # one pass at b utterances: decode time grows a little faster than linearly below the attention-bound range; 1.5x margin + set-up
         est = 15.0 + 1.5 * (out["ms_per_step"] * 1e-3) * b / B
-        if budget.allows(f"big_batch_rows[{b}]", est):
-          out["detail"]["big_batch_rows"].append(big_row(args, b, weights, cfg, nums, rank))
-          _log(f"big batch row B={b} done")
+        r = optional(f"big_batch_rows[{b}]", est, lambda b=b: big_row(args, b, weights, cfg, nums, rank))
+        if r is not None:
+          out["detail"]["big_batch_rows"].append(r)
     out["wall_s"] = time.time() - _T0
     print(json.dumps(out), flush=True)
   dp.finish()
@@ -401,6 +422,8 @@ def big_row(args, b, weights, cfg0, nums, rank):
   torch.cuda.synchronize()
   dt = time.perf_counter() - t0
   pre_ms, dec_ms = wl.split_ms(1)
+  wl.eng = None
+  eng.close()
   del wl, eng
   torch.cuda.empty_cache()
   return {"utterances": b, "prefill_pack": pack, "passes": 1, "seconds_per_pass": dt, "tokens_per_s": b * (args.decode_steps + 1) / dt,
@@ -492,6 +515,8 @@ def batch_row(args, b, weights, prompts_dev, nums):
   torch.cuda.synchronize()
   t2 = time.perf_counter()
   wl.release_all()
+  wl.eng = None
+  eng.close()
   del eng
   ms_step = (t2 - t1) / args.decode_steps * 1e3
   mean_ctx = args.prefill_len + args.decode_steps / 2.0
@@ -533,6 +558,7 @@ def long_prefill_row(args, weights, nums, total=4096, chunk=None):
   t0 = time.perf_counter()
   run()
   dt = time.perf_counter() - t0
+  eng.close()
   del eng
   flops = 2.0 * total * nums["body_params"] + 4.0 * 16 * 128 * 16 * total * total / 2 + (total // P) * 2.0 * nums["unembed_params"]
   return {"prompt_tokens": total, "chunk": P, "seconds": dt, "prefill_tokens_per_s": total / dt, "mfu": flops / dt / MFMA_BF16_PEAK}

@@ -4,6 +4,7 @@
 #include "ixt_kernels.h"
 #include "ixt_gemma_kernels.h"
 #include "ixt_moe_kernels.h"
+#include "ixt_small.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -100,6 +101,10 @@ struct ixt_ctx {
   int attn_tile = 1;         // prefill rows: tiled attention (k_attn_tile) from attn_tile_min_rows rows on
   int attn_tile_min_rows = 64;
   int attn_wave_pairs = 0;   // measured at 256 rows, 765 keys: 339 us per launch (4.7 TB/s) against 305 us (5.3 TB/s) for the block form
+  // few rows (one row block): five launches per layer (ixt_small.h).  small_rows: most rows of that path (0: off); small_tpb: column tiles per
+  // block of k_sdot (0: by shape); small_attn_waves: waves per (row, kv head) block of k_attn_small (4: k_attn_decode instead)
+  int small_rows = 16, small_tpb = 0, small_attn_waves = 16, small_attn_max_blocks = 512;
+  int dot_small = 0;         // ixt_op_dot through k_sdot where it fits (tests)
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   // Gemma-2 block (ixt_config.decoder_block == 1): L counts (attention, MLP) sub-layers, two per reference layer (even: local sliding)
@@ -168,6 +173,8 @@ static void host_rope_tables(const ixt_config& cfg, float max_timescale, std::ve
       cs[(size_t)p * half + i] = f2bf_h((float)cos((double)ang));
     }
 }
+
+static int sdot_set_attributes();
 
 extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (!cfg || !out) return set_err(IXT_ERR_INVALID, "null argument");
@@ -343,6 +350,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   g.Tmax = x->Tmax; g.nsb_max = x->nsb_max;
   hipLaunchKernelGGL(k_pages_reset, dim3(1), dim3(64), 0, 0, x->ps);
   if (hipDeviceSynchronize() != hipSuccess) return fail(set_err(IXT_ERR_HIP, "page state init failed"));
+  if (sdot_set_attributes() != IXT_OK) return fail(IXT_ERR_HIP);
   *out = x;
   return IXT_OK;
 }
@@ -1100,6 +1108,88 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
 
+// ---- few rows: k_sdot / k_attn_small (ixt_small.h)
+struct SdotPlan { int chains, tpb, rpl; size_t lds; bool ok; };
+static SdotPlan sdot_plan(const ixt_ctx* c, int epi, bool norm, int K, int N, int R) {
+  SdotPlan p{};
+  p.chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
+  p.rpl = 0;
+  while ((1 << p.rpl) < R) ++p.rpl;
+  const int ntile = N / 16;
+  int tpb = c->small_tpb > 0 ? c->small_tpb : (epi == GEPI_SWIGLU ? 2 : 1);
+  if (epi == GEPI_SWIGLU && (tpb & 1)) ++tpb;
+  while (tpb > 1 && p.chains * tpb > 16) tpb -= (epi == GEPI_SWIGLU ? 2 : 1);
+  if (tpb > ntile) tpb = ntile;
+  p.tpb = tpb;
+  const int nblk = (K / 8 + 63) / 64;
+  p.lds = ((size_t)(K / 8) << p.rpl) * 16 + (size_t)p.chains * tpb * 1024 + (norm ? (size_t)R * nblk * 4 + 16 : 0);
+  p.ok = R >= 1 && R <= 16 && K % IXT_MK == 0 && N % 16 == 0 && p.chains * tpb <= 16 && tpb >= 1 && (epi != GEPI_SWIGLU || tpb % 2 == 0) && p.lds <= 150 * 1024;
+  return p;
+}
+
+template <int EPI, bool NORM>
+static int sdot_t(const SdotArgs& a, const SdotPlan& p, hipStream_t st) {
+  const int ntile = a.N / 16;
+  hipLaunchKernelGGL((k_sdot<EPI, NORM>), dim3((ntile + p.tpb - 1) / p.tpb), dim3(64 * p.chains * p.tpb), p.lds, st, a);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+
+// up to 156 KiB of dynamic LDS (the down projection keeps R x mlp_dim activations on chip): the attribute once per kernel, at ixt_create
+static int sdot_set_attributes() {
+  static bool done = false;
+  if (done) return IXT_OK;
+#define SATTR(E_, N_) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sdot<E_, N_>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024))
+  SATTR(GEPI_QKV, true); SATTR(GEPI_QKV, false); SATTR(GEPI_RESID, true); SATTR(GEPI_RESID, false);
+  SATTR(GEPI_SWIGLU, true); SATTR(GEPI_SWIGLU, false); SATTR(GEPI_F32, true); SATTR(GEPI_F32, false);
+#undef SATTR
+  done = true;
+  return IXT_OK;
+}
+
+// x: NORM: hidden rows [R][K] row-major (+ scale); else activations in xidx layout.  w: widx layout.
+static int launch_sdot(ixt_ctx* c, int epi, bool norm, const bf16_t* x, const bf16_t* scale, const bf16_t* w, int K, int N, int R, const GemmEpi& e,
+                       hipStream_t st) {
+  const SdotPlan p = sdot_plan(c, epi, norm, K, N, R);
+  if (!p.ok) return set_err(IXT_ERR_UNSUPPORTED, "sdot: %d rows x K %d x N %d does not fit the few-rows form", R, K, N);
+  SdotArgs a;
+  a.x = x; a.scale = scale; a.eps = c->cfg.normalization_layer_epsilon; a.w = reinterpret_cast<const u32x4*>(w);
+  a.K = K; a.N = N; a.R = R; a.rpl = p.rpl; a.tpb = p.tpb; a.chains = p.chains; a.e = e;
+  const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0);
+  int rc = IXT_ERR_UNSUPPORTED;
+  if (epi == GEPI_QKV) rc = norm ? sdot_t<GEPI_QKV, true>(a, p, st) : sdot_t<GEPI_QKV, false>(a, p, st);
+  else if (epi == GEPI_RESID) rc = norm ? sdot_t<GEPI_RESID, true>(a, p, st) : sdot_t<GEPI_RESID, false>(a, p, st);
+  else if (epi == GEPI_SWIGLU) rc = norm ? sdot_t<GEPI_SWIGLU, true>(a, p, st) : sdot_t<GEPI_SWIGLU, false>(a, p, st);
+  else if (epi == GEPI_F32) rc = norm ? sdot_t<GEPI_F32, true>(a, p, st) : sdot_t<GEPI_F32, false>(a, p, st);
+  timing_end(c, st, ti);
+  return rc;
+}
+
+template <int HD, int GQ>
+static void launch_attn_small_t(ixt_ctx* c, int layer, int R, hipStream_t st) {
+  const AttnGeom& g = c->geom;
+  DecAttnArgs da{};
+  da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
+  da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
+  da.kpages = c->kpages_l[layer]; da.vpages = c->vpages_l[layer];
+  da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
+  const size_t lds = sizeof(float) * ((size_t)GQ * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * HD);
+  // sixteen waves leave 128 registers per lane: enough for one query head per kv head; grouped heads take eight waves
+  if (GQ == 1 && c->small_attn_waves >= 16) hipLaunchKernelGGL((k_attn_small<HD, 1, 16>), dim3(g.nkv, R), dim3(1024), lds, st, da);
+  else hipLaunchKernelGGL((k_attn_small<HD, GQ, 8>), dim3(g.nkv, R), dim3(512), lds, st, da);
+}
+static bool attn_small_fits(const ixt_ctx* c, int R) {
+  const AttnGeom& g = c->geom;
+  const size_t lds = sizeof(float) * ((size_t)c->GQ * c->D + (size_t)c->GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * c->D);
+  return c->small_attn_waves >= 8 && (long)R * c->KV <= c->small_attn_max_blocks && lds <= 64 * 1024 && (c->D == 128 || c->D == 64) && (c->GQ == 1 || c->GQ == 2 || c->GQ == 4);
+}
+static int launch_attn_small(ixt_ctx* c, int layer, int R, hipStream_t st) {
+#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn_small_t<HD_, GQ_>(c, layer, R, st); LAUNCHCHK(); return IXT_OK; }
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
+}
+
 // decoders.py:552-565 on nl rows of f32 logits in place (/ sqrt(emb), soft cap), then the greedy choice over the allowed columns of the
 // post-processed values (the cap is not strictly monotone after rounding, so the maximum is taken after it).
 static int launch_logits_post(ixt_ctx* c, float* lg, int nl, int normalize, float cap, int32_t* argmax_out, hipStream_t st) {
@@ -1193,10 +1283,72 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
 //                       slice leaves the chip;
 //   fewer rows          split-K dots into f32 slices: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum
 //                       + residual + norm), dot_wi, swiglu, dot_wo, rownorm (slice sum + residual + next norm).
+// Few rows (R <= 16, llama2 block): five launches per layer, nothing but K / V pages, q, the attention output and the hidden rows leaves the chip
+// between them (ixt_small.h).  Same results as the other forms bit for bit (tests/test_gpu_small.py compares the two paths of one engine).
+static bool small_path_ok(const ixt_ctx* c, int R) {
+  if (c->small_rows <= 0 || R > c->small_rows || R > 16 || c->moe || c->gemma) return false;
+  return sdot_plan(c, GEPI_QKV, true, c->E, c->NQKV, R).ok && sdot_plan(c, GEPI_RESID, false, c->QN, c->E, R).ok &&
+         sdot_plan(c, GEPI_SWIGLU, true, c->E, 2 * c->F, R).ok;
+}
+static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
+                              float* logits_out, bool decode, hipStream_t st) {
+  const int E = c->E, F = c->F;
+  bf16_t* hcur = c->h_a;
+  bf16_t* hnext = c->h_b;
+  const bool down_small = sdot_plan(c, GEPI_RESID, false, F, E, R).ok;
+  const bool attn_small = attn_small_fits(c, R);
+  const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
+  TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, nullptr, nullptr, st));   // hidden rows = embedding rows (no norm: the QKV kernel norms)
+  for (int l = 0; l < c->L; ++l) {
+    const LayerW& w = c->layers[l];
+    GemmEpi e{};
+    e.row_slot = c->row_slot; e.row_pos = c->row_pos; e.row_active = c->row_active; e.page_map = c->ps.page_map;
+    e.rope_sin = c->rope_sin; e.rope_cos = c->rope_cos; e.qbuf = c->qbuf; e.kpages = c->kpages_l[l]; e.vpages = c->vpages_l[l]; e.g = c->geom;
+    TRY(launch_sdot(c, GEPI_QKV, true, hcur, w.ln1, w.wqkv, E, c->NQKV, R, e, st));
+    {
+      const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
+      if (attn_small) {
+        TRY(launch_attn_small(c, l, R, st));
+      } else if (fused_lds <= 64 * 1024) {
+        TRY(launch_attention_fused(c, l, R, DotResult{0, 0, 0}, false, st));
+      } else {
+        TRY(launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st));
+        hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
+        LAUNCHCHK();
+      }
+      timing_end(c, st, ta);
+    }
+    GemmEpi eo{};
+    eo.h_in = hcur; eo.h_out = hnext;
+    TRY(launch_sdot(c, GEPI_RESID, false, c->ao, nullptr, w.wo, c->QN, E, R, eo, st));
+    GemmEpi eu{};
+    eu.act = c->hact;
+    TRY(launch_sdot(c, GEPI_SWIGLU, true, hnext, w.ln2, w.wi, E, 2 * F, R, eu, st));
+    if (down_small) {
+      GemmEpi ed{};
+      ed.h_in = hnext; ed.h_out = hcur;
+      TRY(launch_sdot(c, GEPI_RESID, false, c->hact, nullptr, w.wout, F, E, R, ed, st));
+    } else {   // R x mlp_dim activations beyond the LDS: split-K slices + slice-sum / residual
+      DotResult dr;
+      TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr, true));
+      hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->part, dr.slices, dr.slice_stride, hnext, hcur, E);
+      LAUNCHCHK();
+    }
+  }
+  if (nl > 0) {
+    if (nl > c->NLmax) return set_err(IXT_ERR_INVALID, "too many logits rows (%d > %d)", nl, c->NLmax);
+    TRY(launch_rownorm(c, 2, nl, nullptr, nullptr, lrows ? hcur : hcur + (size_t)lrow0 * E, nullptr, c->final_norm, c->xn, st, 1, lrows));
+    TRY(launch_unembed(c, c->xn, nl, logits_out, argmax_out, st));
+  }
+  c->h_final = hcur; c->h_final_rows = R;
+  return IXT_OK;
+}
+
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
   if (c->gemma) return forward_rows_gemma2(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, st);
+  if (small_path_ok(c, R)) return forward_rows_small(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, decode, st);
   const int E = c->E, F = c->F;
   DotResult dr;
   bf16_t* hcur = c->h_a;
@@ -1483,6 +1635,11 @@ extern "C" int ixt_op_dot(ixt_ctx* c, const uint16_t* x, const uint16_t* w, floa
     e.out = c->part;
     TRY(launch_ring(c, GEPI_F32, c->xt_op, c->wt_op, K, N, R, e, false, st, 1));
     dr.slices = 1; dr.slice_stride = (size_t)R * N; dr.ntiles = N / 16;
+  } else if (c->dot_small && sdot_plan(c, GEPI_F32, false, K, N, R).ok && (size_t)R * N <= c->part_floats) {   // the few-rows form, f32 epilogue (tests)
+    GemmEpi e{};
+    e.out = c->part;
+    TRY(launch_sdot(c, GEPI_F32, false, c->xt_op, nullptr, c->wt_op, K, N, R, e, st));
+    dr.slices = 1; dr.slice_stride = (size_t)R * N; dr.ntiles = N / 16;
   } else
   TRY(launch_dot(c, c->xt_op, c->wt_op, K, N, R, c->part, c->part_floats, false, st, &dr));
   const size_t n = (size_t)R * N;
@@ -1650,6 +1807,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

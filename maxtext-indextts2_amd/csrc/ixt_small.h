@@ -1,0 +1,414 @@
+// ixt_small.h -- the decode step at FEW rows (one row block: R <= 16), five launches per layer (included by ixt_api.hip after ixt_gemm.h):
+//
+//   k_sdot<QKV, norm>     RMSNorm of the hidden rows (recomputed per block) -> QKV projection -> RoPE -> q buffer, K / V pages
+//   k_attn_small<NW>      one block of NW (16) waves per (row, kv head): scores, softmax statistics, PV, in-order super-block sums
+//   k_sdot<RESID>         output projection + residual
+//   k_sdot<SWIGLU, norm>  RMSNorm -> (wi_0, wi_1) projection -> SwiGLU
+//   k_sdot<RESID>         down projection + residual
+//
+// Why: below ~64 rows every kernel of the layer is a weight stream whose time is one memory latency plus bytes / bandwidth, and the
+// split-K form of the larger batches (k_dotb: one f32 slice per 512-k chain, then slice-sum / residual / norm and SwiGLU kernels) pays
+// 8 launches per layer for 68 us of kernels against 28 us of HBM time (profiles/r02_b8_by_grid.txt).  Here a block owns ALL chains of
+// its column tiles (one wave per chain: every weight byte of the launch is requested in the first microsecond), the chain totals meet in
+// LDS and are added in chain order by one wave, and the epilogue of ixt_gemm.h's ring GEMMs runs on chip: no slice leaves the chip.
+// The arithmetic is the canonical dot's (chain c: 16 v_mfma_f32_16x16x32_bf16 over k in [512c, 512c+512) into one accumulator;
+// t = 0; t += chain(c), c ascending), so the results equal the other forms' bit for bit.
+//
+// Activations in LDS, row-compact: piece (kc, r) = the 8 bf16 of row r at k = 8 kc .. 8 kc + 7 lives at sx[(kc << rpl) + r], Rp = 1 << rpl
+// >= R rows per k-chunk (HBM holds 16-row fragments whatever R is; only the R real rows are fetched).  The MFMA's B operand of lane
+// (r_in, kq) at step s is piece (4 (16 c + s) + kq, r_in mod Rp): rows r_in >= R compute garbage that is never stored (an MFMA output
+// row depends on its own B column only).  ds_read_b128 of that pattern is conflict-free for every Rp (MI355X_MICROARCH.md, LDS).
+#pragma once
+
+struct SdotArgs {
+  const bf16_t* x;       // NORM = false: [K/8][16][8] (xidx layout, row block 0); NORM = true: hidden rows [R][K] row-major
+  const bf16_t* scale;   // NORM: RMSNorm scale [K]
+  float eps;
+  const u32x4* w;        // widx layout
+  int K, N, R, rpl, tpb, chains;
+  GemmEpi e;
+};
+
+template <int EPI, bool NORM>
+__global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 sx[];
+  const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps (tile, chain) and every branch on them scalar
+  const int K = a.K, N = a.N, R = a.R, tpb = a.tpb, chains = a.chains;
+  const int nsteps = K >> 5, ntile = N >> 4, nch = K >> 3;
+  const int rpl = a.rpl, Rp = 1 << rpl;
+  const int t = wave % tpb, c = wave / tpb;
+  const int tile = blockIdx.x * tpb + t;
+  const bool tile_ok = tile < ntile;
+  const int r_in = lane & 15, cq = lane >> 4;
+  f32x4* red = reinterpret_cast<f32x4*>(sx + ((size_t)nch << rpl));     // [chains][tpb][64]
+  float* blk = reinterpret_cast<float*>(red + (size_t)chains * tpb * 64);   // NORM: [R][nblk] block sums of squares
+
+  // this wave's chain of weight fragments: everything in flight before anything else happens
+  const int s0 = c * 16, cs = min(16, nsteps - s0);
+  const u32x4* wbase = a.w + ((size_t)(tile_ok ? tile : 0) * nsteps + s0) * 64 + lane;
+  const bool full = tile_ok && cs == 16;      // the usual case: a whole chain, no per-step conditions anywhere
+  u32x4 wv[16];
+  // (a short last chain re-reads its last fragment for the steps it does not have, a block past the last tile reads tile 0: valid
+  // addresses, values never used -- one unconditional load sequence for every wave)
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wv[s] = __builtin_nontemporal_load(wbase + (size_t)min(s, cs - 1) * 64);
+
+  if constexpr (NORM) {
+    // RMSNorm (normalizations.py:57-70) in the canonical order of k_rownorm: chunk of 8 = one fma chain, block of 64 chunks by
+    // xor-butterfly, blocks added in order; y = bf16(x r), out = bf16(y scale).  A wave takes (row, block) pairs; lane = chunk.
+    const int nblk = (nch + 63) >> 6, nw = nthr >> 6;
+    for (int p = wave; p < R * nblk; p += nw) {
+      const int row = p / nblk, b = p - row * nblk, ch = b * 64 + lane;
+      float v = 0.0f;
+      if (ch < nch) {
+        const u32x4 hv = *reinterpret_cast<const u32x4*>(a.x + (size_t)row * K + ch * 8);
+        const float h[8] = {bflo(hv.x), bfhi(hv.x), bflo(hv.y), bfhi(hv.y), bflo(hv.z), bfhi(hv.z), bflo(hv.w), bfhi(hv.w)};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v = __builtin_fmaf(h[j], h[j], v);
+        sx[((size_t)ch << rpl) + row] = hv;
+      }
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
+      if (lane == 0) blk[row * nblk + b] = v;
+    }
+    __syncthreads();
+    for (int p = tid; p < nch << rpl; p += nthr) {
+      const int ch = p >> rpl, row = p & (Rp - 1);
+      if (row < R) {
+        float total = 0.0f;
+        for (int b = 0; b < nblk; ++b) total = total + blk[row * nblk + b];
+        const float rs = 1.0f / sqrtf(total / (float)K + a.eps);
+        const u32x4 hv = sx[p];
+        const u32x4 sv = *reinterpret_cast<const u32x4*>(a.scale + ch * 8);
+        const float h[8] = {bflo(hv.x), bfhi(hv.x), bflo(hv.y), bfhi(hv.y), bflo(hv.z), bfhi(hv.z), bflo(hv.w), bfhi(hv.w)};
+        const float sc[8] = {bflo(sv.x), bfhi(sv.x), bflo(sv.y), bfhi(sv.y), bflo(sv.z), bfhi(sv.z), bflo(sv.w), bfhi(sv.w)};
+        bf16_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = f2bf(rbf(h[j] * rs) * sc[j]);
+        u32x4 ov;
+        ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
+        sx[p] = ov;
+      }
+    }
+  } else {
+    // rows 0 .. Rp - 1 of the activation fragments (rows R .. Rp - 1 are whatever the producer left there: never used), 4 pieces per
+    // thread and round, loads first; unconditional loads from clamped addresses keep the loop free of carried registers
+    const u32x4* xg = reinterpret_cast<const u32x4*>(a.x);
+    const int np = nch << rpl;
+#pragma unroll 1
+    for (int p0 = tid; p0 < np; p0 += 4 * nthr) {
+      u32x4 tmp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = min(p0 + u * nthr, np - 1);
+        tmp[u] = xg[(size_t)(p >> rpl) * 16 + (p & (Rp - 1))];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = p0 + u * nthr;
+        if (p < np) sx[p] = tmp[u];
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 acc = f32x4(0.0f);
+  {
+    const u32x4* xb = sx + (((size_t)s0 * 4 + cq) << rpl) + (r_in & (Rp - 1));
+    if (full) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[s]), __builtin_bit_cast(bf16x8, xb[(size_t)(s * 4) << rpl]), acc, 0, 0, 0);
+        if ((s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // at most four operand reads ahead of their MFMAs: 64 registers hold the weight fragments
+      }
+    } else if (tile_ok) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s)
+        if (s < cs) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wv[s]), __builtin_bit_cast(bf16x8, xb[(size_t)(s * 4) << rpl]), acc, 0, 0, 0);
+    }
+  }
+  red[((size_t)c * tpb + t) * 64 + lane] = acc;
+  __syncthreads();
+  if (c != 0 || !tile_ok) return;
+  if (EPI == GEPI_SWIGLU && (t & 1)) return;        // the wi_1 tile's totals are taken by the wi_0 tile's wave
+  f32x4 tot = f32x4(0.0f), tot2 = f32x4(0.0f);
+  for (int cc = 0; cc < chains; ++cc) {
+    tot = tot + red[((size_t)cc * tpb + t) * 64 + lane];
+    if (EPI == GEPI_SWIGLU) tot2 = tot2 + red[((size_t)cc * tpb + t + 1) * 64 + lane];
+  }
+  const int row = r_in;
+  const bool row_ok = row < R;
+
+  if constexpr (EPI == GEPI_F32) {
+    if (row_ok) *reinterpret_cast<float4*>(a.e.out + (size_t)row * N + tile * 16 + cq * 4) = make_float4(tot[0], tot[1], tot[2], tot[3]);
+  } else if constexpr (EPI == GEPI_RESID) {
+    if (row_ok) {
+      const size_t o = (size_t)row * N + tile * 16 + cq * 4;
+      const uint2 hv = *reinterpret_cast<const uint2*>(a.e.h_in + o);
+      uint2 ov;
+      ov.x = pack2(f2bf(bflo(hv.x) + rbf(tot[0])), f2bf(bfhi(hv.x) + rbf(tot[1])));
+      ov.y = pack2(f2bf(bflo(hv.y) + rbf(tot[2])), f2bf(bfhi(hv.y) + rbf(tot[3])));
+      *reinterpret_cast<uint2*>(a.e.h_out + o) = ov;
+    }
+  } else if constexpr (EPI == GEPI_SWIGLU) {
+    if (row_ok && tile + 1 < ntile) {
+      const int F = N >> 1, f0 = (tile >> 1) * 16 + cq * 4;
+      bf16_t o[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = ixt_swiglu(rbf(tot[j]), rbf(tot2[j]));
+      uint2 ov;
+      ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(a.e.act + xidx(row, f0, F)) = ov;
+    }
+  } else if constexpr (EPI == GEPI_QKV) {
+    // as GEPI_QKV of k_gemm_ring: bf16(t), RoPE by partner exchange across lanes l and l ^ 32, q -> qbuf, K / V -> the row's page
+    const AttnGeom& g = a.e.g;
+    const int half = g.hd >> 1, tph = g.hd >> 4;
+    const int QN = g.nq * g.hd, KN = g.nkv * g.hd;
+    const int pos = row_ok ? a.e.row_pos[row] : 0;
+    const bool wr_kv = row_ok && a.e.row_active[row] != 0;
+    int page = 0;
+    if (wr_kv) page = a.e.page_map[(size_t)a.e.row_slot[row] * g.mpg + pos / g.P];
+    const int tok = pos % g.P;
+    const int col0 = tile * 16;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = rbf(tot[j]);
+    const bool is_v = col0 >= QN + KN;
+    const int hh = col0 / g.hd, th = tile % tph;
+    if (!is_v) {
+      const int fi = 8 * th + 4 * (cq & 1);
+      float sn[4], cs_[4];
+      {
+        const uint2 sv = *reinterpret_cast<const uint2*>(a.e.rope_sin + (size_t)pos * half + fi);
+        const uint2 cv = *reinterpret_cast<const uint2*>(a.e.rope_cos + (size_t)pos * half + fi);
+        sn[0] = bflo(sv.x); sn[1] = bfhi(sv.x); sn[2] = bflo(sv.y); sn[3] = bfhi(sv.y);
+        cs_[0] = bflo(cv.x); cs_[1] = bfhi(cv.x); cs_[2] = bflo(cv.y); cs_[3] = bfhi(cv.y);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float other = __shfl_xor(v[j], 32, 64);
+        v[j] = cq < 2 ? rbf(rbf(v[j] * cs_[j]) - rbf(other * sn[j])) : rbf(rbf(v[j] * cs_[j]) + rbf(other * sn[j]));
+      }
+    }
+    if (!row_ok) return;
+    uint2 ov;
+    ov.x = pack2(f2bf(v[0]), f2bf(v[1])); ov.y = pack2(f2bf(v[2]), f2bf(v[3]));
+    if (hh < g.nq) {
+      const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
+      *reinterpret_cast<uint2*>(a.e.qbuf + ((size_t)row * g.nq + hh) * g.hd + feat) = ov;
+    } else if (!is_v) {
+      if (wr_kv) {
+        const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
+        *reinterpret_cast<uint2*>(a.e.kpages + kpage_off(g, page, hh - g.nq, feat >> 3, tok) + (feat & 7)) = ov;
+      }
+    } else if (wr_kv) {
+      const int feat = th * 16 + cq * 4;
+      *reinterpret_cast<uint2*>(a.e.vpages + vpage_off(g, page, hh - g.nq - g.nkv, tok) + feat) = ov;
+    }
+  }
+}
+
+// =====================================================================================================
+// Decode attention for few rows: k_attn_decode<HD, GQ, false> with NW waves per (row, kv head) block instead of four.  With R x nkv blocks
+// below the CU count a block is alone on its CU, and its time is the length of ITS serial chain: key tiles per wave, then the softmax, then
+// value groups per wave.  Sixteen waves cut the two streams to a quarter and put four times the bytes in flight per CU.  Same operation
+// order (scores: one fma chain over d; l: page sums in key order, pages in order; PV: page chains, 4 pages per super-block in order,
+// super-blocks in order).  q from qbuf, every key / value from the pages.  grid = (nkv, R), block 64 NW,
+// LDS = GQ HD + GQ Tmax' + mpg' + 16 + nsb_max HD floats.
+// =====================================================================================================
+template <int HD, int GQ, int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int NT = NW * 64;
+  const AttnGeom& g = a.g;
+  const int kvh = blockIdx.x, r = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_out = g.nq * HD;
+  if (!a.row_active[r]) {
+    for (int i = tid; i < GQ * HD; i += NT) a.out[xidx(r, kvh * GQ * HD + i, n_out)] = 0;
+    return;
+  }
+  float* qs = sm;                               // [GQ][HD]
+  float* ebuf = qs + GQ * HD;                   // [GQ][Tmax'] scores -> exps -> P
+  const int tp = (g.Tmax + 3) & ~3;
+  float* psum = ebuf + (size_t)GQ * tp;         // [mpg']
+  float* wred = psum + ((g.mpg + 3) & ~3);      // [16]
+  float* sbs = wred + 16;                       // [nsb_max][HD]
+  const int pos = a.row_pos[r];
+  const int kv_len = pos + 1;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  const int ppw = 64 / g.P;
+  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+
+  constexpr int KH = HD / 16;             // d-chunks per half tile
+  u32x4 ka[KH], kb[KH];
+#define IXT_KLOAD(DST_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = wave + NW * ((F_) >> 1), h_ = (F_) & 1;                                                       \
+    const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
+    if (ps_ * ppw < pages && j_ < kv_len) {                                                                       \
+      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, h_ * KH, lane % g.P);                         \
+      _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
+    }                                                                                                             \
+  } while (0)
+  IXT_KLOAD(ka, 0);
+  IXT_KLOAD(kb, 1);
+  {
+    const bf16_t* qsrc = a.qbuf + ((size_t)r * g.nq + kvh * GQ) * HD;
+    for (int i = tid; i < GQ * HD; i += NT) qs[i] = bf2f(qsrc[i]);
+  }
+  __syncthreads();
+
+#define IXT_KHALF(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = wave + NW * ((F_) >> 1), h_ = (F_) & 1;                                                       \
+    const int j_ = (ps_ * ppw + lane / g.P) * g.P + lane % g.P;                                                   \
+    if (h_ == 0) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = 0.0f; }                                \
+    if (j_ < kv_len) {                                                                                            \
+      _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) {                                                         \
+        const float kf[8] = {bflo(BUF_[dc].x), bfhi(BUF_[dc].x), bflo(BUF_[dc].y), bfhi(BUF_[dc].y),              \
+                             bflo(BUF_[dc].z), bfhi(BUF_[dc].z), bflo(BUF_[dc].w), bfhi(BUF_[dc].w)};             \
+        _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                          \
+          const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8);                   \
+          const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8 + 4);               \
+          float sacc = acc[q];                                                                                    \
+          sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);                     \
+          sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);                     \
+          sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);                     \
+          sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);                     \
+          acc[q] = sacc;                                                                                          \
+        }                                                                                                         \
+      }                                                                                                           \
+      if (h_ == 1) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * tp + j_] = acc[q]; }         \
+    }                                                                                                             \
+  } while (0)
+  {
+    const int ntile = (pages > wave * ppw) ? (pages - wave * ppw + NW * ppw - 1) / (NW * ppw) : 0;
+    float acc[GQ];
+    for (int f = 0; f < 2 * ntile; f += 2) {
+      IXT_KHALF(ka, f);
+      IXT_KLOAD(ka, f + 2);
+      IXT_KHALF(kb, f + 1);
+      IXT_KLOAD(kb, f + 3);
+    }
+  }
+#undef IXT_KHALF
+#undef IXT_KLOAD
+  __syncthreads();
+
+  constexpr int LPP = HD / 8;             // lanes per page (d-chunks)
+  constexpr int PPW = 64 / LPP;           // pages a wave covers at once
+  const int tq = lane / LPP, dc = lane % LPP;
+  const int nb = g.P / 8;                 // batches of 8 tokens per page
+  const int ngrp = (pages > wave * PPW) ? (pages - wave * PPW + NW * PPW - 1) / (NW * PPW) : 0;
+  const int nf = ngrp * nb;
+#define IXT_VLOAD(BUF_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    if (f_ < nf) {                                                                                                \
+      const int p_ = (wave + NW * (f_ / nb)) * PPW + tq, t0_ = (f_ % nb) * 8;                                     \
+      if (p_ < pages) {                                                                                           \
+        const bf16_t* vp_ = a.vpages + vpage_off(g, prow[p_], kvh, t0_) + dc * 8;                                 \
+        const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                        \
+        _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                             \
+          if (u < nt_) BUF_[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)u * HD);                           \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+#define IXT_VBATCH(BUF_, F_)                                                                                      \
+  do {                                                                                                            \
+    const int f_ = (F_);                                                                                          \
+    const int pg0_ = (wave + NW * (f_ / nb)) * PPW, p_ = pg0_ + tq, bt_ = f_ % nb, t0_ = bt_ * 8;                 \
+    if (bt_ == 0) { _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = 0.0f; }                                \
+    if (p_ < pages) {                                                                                             \
+      const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                          \
+      const float* pj_ = e + (size_t)p_ * g.P + t0_;                                                              \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u) {                                                             \
+        if (u < nt_) {                                                                                            \
+          const float vf[8] = {bflo(BUF_[u].x), bfhi(BUF_[u].x), bflo(BUF_[u].y), bfhi(BUF_[u].y),                \
+                               bflo(BUF_[u].z), bfhi(BUF_[u].z), bflo(BUF_[u].w), bfhi(BUF_[u].w)};               \
+          const float pv = pj_[u];                                                                                \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) acc[j] = __builtin_fmaf(pv, vf[j], acc[j]);               \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+    if (bt_ == nb - 1) {                                                                                          \
+      const int sbl = tq / IXT_SB, base_lane = sbl * IXT_SB * LPP + dc;                                           \
+      float ss[8];                                                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = 0.0f;                                                 \
+      _Pragma("unroll") for (int i = 0; i < IXT_SB; ++i) {                                                        \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) ss[j] = ss[j] + __shfl(acc[j], base_lane + i * LPP, 64);    \
+      }                                                                                                           \
+      const int sb = pg0_ / IXT_SB + sbl;                                                                         \
+      if (tq % IXT_SB == 0 && sb < nsb) {                                                                         \
+        float* dst = sbs + (size_t)sb * HD + dc * 8;                                                              \
+        *reinterpret_cast<float4*>(dst) = make_float4(ss[0], ss[1], ss[2], ss[3]);                                \
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(ss[4], ss[5], ss[6], ss[7]);                            \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  for (int q = 0; q < GQ; ++q) {
+    float* e = ebuf + (size_t)q * tp;
+    u32x4 va[8], vb[8];
+    IXT_VLOAD(va, 0);
+    IXT_VLOAD(vb, 1);
+    float m = -INFINITY;
+    for (int j = tid; j < kv_len; j += NT) m = fmaxf(m, e[j]);
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) wred[wave] = m;
+    __syncthreads();
+    m = wred[0];
+#pragma unroll
+    for (int w2 = 1; w2 < NW; ++w2) m = fmaxf(m, wred[w2]);
+    for (int j = tid; j < kv_len; j += NT) e[j] = ixt_exp(e[j] - m);
+    __syncthreads();
+    for (int p = tid; p < pages; p += NT) {
+      float sacc = 0.0f;
+      const float* ep = e + (size_t)p * g.P;
+      const int n = min(g.P, kv_len - p * g.P);
+      int t0 = 0;
+      for (; t0 + 8 <= n; t0 += 8) {
+        const float4 x0 = *reinterpret_cast<const float4*>(ep + t0), x1 = *reinterpret_cast<const float4*>(ep + t0 + 4);
+        sacc = sacc + x0.x; sacc = sacc + x0.y; sacc = sacc + x0.z; sacc = sacc + x0.w;
+        sacc = sacc + x1.x; sacc = sacc + x1.y; sacc = sacc + x1.z; sacc = sacc + x1.w;
+      }
+      for (; t0 < n; ++t0) sacc = sacc + ep[t0];
+      psum[p] = sacc;
+    }
+    __syncthreads();
+    float l = 0.0f;
+    {
+      int p = 0;
+      for (; p + 4 <= pages; p += 4) {
+        const float4 x0 = *reinterpret_cast<const float4*>(psum + p);
+        l = l + x0.x; l = l + x0.y; l = l + x0.z; l = l + x0.w;
+      }
+      for (; p < pages; ++p) l = l + psum[p];
+    }
+    for (int j = tid; j < kv_len; j += NT) e[j] = rbf(e[j] / l);
+    __syncthreads();
+    float acc[8];
+    for (int f = 0; f < nf; f += 2) {
+      IXT_VBATCH(va, f);
+      IXT_VLOAD(va, f + 2);
+      if (f + 1 < nf) {
+        IXT_VBATCH(vb, f + 1);
+        IXT_VLOAD(vb, f + 3);
+      }
+    }
+    __syncthreads();
+    if (tid < HD) {
+      float t = 0.0f;
+      for (int sb = 0; sb < nsb; ++sb) t = t + sbs[(size_t)sb * HD + tid];
+      a.out[xidx(r, (kvh * GQ + q) * HD + tid, n_out)] = f2bf(t);
+    }
+    __syncthreads();
+  }
+#undef IXT_VLOAD
+#undef IXT_VBATCH
+}

@@ -168,6 +168,14 @@ class MaxEngine(engine_api.Engine):
     _lib.check(self.lib.ixt_pages_status(self._ctx, out, 0, ctypes.c_void_p(_stream_ptr())))
     self._raise_if_new_failure(out[0], out[1], what)
 
+  def close(self) -> None:
+    """Give the engine's HBM (weights copy, page pools, workspaces) back now; the engine cannot be used afterwards.  Handles returned by
+    earlier calls keep a reference to the engine object, so waiting for the garbage collector can hold 100+ GB for a long time."""
+    if getattr(self, "_ctx", None) is not None and self._ctx:
+      torch.cuda.synchronize()
+      self.lib.ixt_destroy(self._ctx)
+      self._ctx = None
+
   def __del__(self):
     try:
       if getattr(self, "_ctx", None) is not None and self._ctx:

@@ -144,6 +144,24 @@ def test_dot_ring_split_kernel(ctx, R, K, N):
     H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"ring_split", 0))
 
 
+@pytest.mark.parametrize("tpb", [0, 2, 4])
+@pytest.mark.parametrize("R,K,N", [(1, 256, 512), (3, 128, 16), (8, 384, 528), (5, 1024, 1536), (16, 2048, 272), (2, 640, 512), (7, 1152, 256),
+                                   (8, 7168, 64), (1, 7168, 48), (13, 2048, 1008), (4, 512, 64)])
+def test_dot_small_rows_kernel(ctx, R, K, N, tpb):
+  """The few-rows form (csrc/ixt_small.h k_sdot, f32 epilogue): one wave per 512-k chain, chain totals added in order on chip; one to
+  sixteen rows (row-compact activations in LDS), one chain, several, a short last chain (640, 1152), fourteen chains (the MLP down
+  projection's K at C2), a partial last block of tiles; 1, 2 and 4 column tiles per block."""
+  eng = ctx["eng"]
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_small", 1))
+  H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"small_tpb", tpb))
+  try:
+    rng = np.random.default_rng(R * 1000 + K + N + tpb)
+    _dot_case(ctx, H.rand_bf16(rng, (R, K)), H.rand_bf16(rng, (K, N), 0.05))
+  finally:
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"dot_small", 0))
+    H.lib.check(eng.lib.ixt_set_option(eng._ctx, b"small_tpb", 0))
+
+
 @pytest.mark.parametrize("spread,zero_frac", [(4, 0.0), (12, 0.2), (40, 0.05)])
 def test_dot_wide_exponents_and_zeros(ctx, spread, zero_frac):
   """The matrix-core arithmetic truncates small products against the largest one of each 8-k step: exercise wide exponent
