@@ -221,6 +221,10 @@ int ixt_op_unembed_argmax(ixt_ctx* ctx, const uint16_t* y, int R, float* logits,
  * logits f32[rows][vocab] (the rounded logits ixt_prefill_chunk / ixt_generate / ixt_op_unembed_argmax write), chosen int32[rows] ->
  * out f32[rows] = log_softmax(logits[r])[chosen[r]]. */
 int ixt_op_logprob(ixt_ctx* ctx, const float* logits_dev, int rows, const int32_t* chosen_dev, float* out_dev, void* stream);
+/* Self-check of the f32 -> bf16 rounding every kernel uses (jax's astype(bfloat16): round to nearest even; the reference's dtype choice,
+ * base.yml:86): the hardware conversion against the integer formula over all 2^32 inputs -> number of differing non-NaN inputs plus
+ * NaN inputs that do not stay NaN (0 expected). */
+int ixt_op_cvt_check(ixt_ctx* ctx, int64_t* mismatches_out, void* stream);
 /* Gather a slot's K and V of one layer to dense bf16[length][nkv][hd] device arrays (cache export). */
 int ixt_kv_gather(ixt_ctx* ctx, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream);
 /* RoPE tables (bf16 bit patterns) to HOST arrays [max_target_length][head_dim/2]. */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ixt_op_kv_write": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, vp, ctypes.c_int, vp]),
     "ixt_op_paged_attention": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
     "ixt_op_unembed_argmax": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
+    "ixt_op_cvt_check": (ctypes.c_int, [vp, c_i64p, vp]),
     "ixt_kv_gather": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "ixt_rope_tables": (ctypes.c_int, [vp, c_u16p, c_u16p]),
     "ixt_timing_enable": (ctypes.c_int, [vp, ctypes.c_int]),

@@ -105,6 +105,7 @@ struct ixt_ctx {
   // block of k_sdot (0: by shape); small_attn_waves: waves per (row, kv head) block of k_attn_small (4: k_attn_decode instead)
   int small_rows = 16, small_tpb = 0, small_attn_waves = 16, small_attn_max_blocks = 512;
   int dot_small = 0;         // ixt_op_dot through k_sdot where it fits (tests)
+  int small_norm = 1;        // 1: the RMSNorm in front of the QKV / wi projections runs inside k_sdot; 0: k_rownorm launches (experiments)
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
   // Gemma-2 block (ixt_config.decoder_block == 1): L counts (attention, MLP) sub-layers, two per reference layer (even: local sliding)
@@ -1116,14 +1117,16 @@ static SdotPlan sdot_plan(const ixt_ctx* c, int epi, bool norm, int K, int N, in
   p.rpl = 0;
   while ((1 << p.rpl) < R) ++p.rpl;
   const int ntile = N / 16;
-  int tpb = c->small_tpb > 0 ? c->small_tpb : (epi == GEPI_SWIGLU ? 2 : 1);
+  // tiles per block: the blocks of a norm-fused launch each norm the rows for themselves, two tiles share that (QKV at C2, 8 rows:
+  // 11.3 us with two tiles per block against 14.3 with one; the plain forms are fastest with one: profiles/r03_b8_by_grid.txt)
+  int tpb = c->small_tpb > 0 ? c->small_tpb : ((epi == GEPI_SWIGLU || norm) ? 2 : 1);
   if (epi == GEPI_SWIGLU && (tpb & 1)) ++tpb;
   while (tpb > 1 && p.chains * tpb > 16) tpb -= (epi == GEPI_SWIGLU ? 2 : 1);
   if (tpb > ntile) tpb = ntile;
   p.tpb = tpb;
   const int nblk = (K / 8 + 63) / 64;
-  p.lds = ((size_t)(K / 8) << p.rpl) * 16 + (size_t)p.chains * tpb * 1024 + (norm ? (size_t)R * nblk * 4 + 16 : 0);
-  p.ok = R >= 1 && R <= 16 && K % IXT_MK == 0 && N % 16 == 0 && p.chains * tpb <= 16 && tpb >= 1 && (epi != GEPI_SWIGLU || tpb % 2 == 0) && p.lds <= 150 * 1024;
+  p.lds = ((size_t)(K / 8) << p.rpl) * 16 + (size_t)p.chains * tpb * 1024 + (norm ? 1024 + (size_t)(K / 8) * 16 : 0);
+  p.ok = R >= 1 && R <= 16 && R * nblk <= 240 && K % IXT_MK == 0 && N % 16 == 0 && p.chains * tpb <= 16 && tpb >= 1 && (epi != GEPI_SWIGLU || tpb % 2 == 0) && p.lds <= 150 * 1024;
   return p;
 }
 
@@ -1173,19 +1176,17 @@ static void launch_attn_small_t(ixt_ctx* c, int layer, int R, hipStream_t st) {
   da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
   da.kpages = c->kpages_l[layer]; da.vpages = c->vpages_l[layer];
   da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
-  const size_t lds = sizeof(float) * ((size_t)GQ * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * HD);
-  // sixteen waves leave 128 registers per lane: enough for one query head per kv head; grouped heads take eight waves
-  if (GQ == 1 && c->small_attn_waves >= 16) hipLaunchKernelGGL((k_attn_small<HD, 1, 16>), dim3(g.nkv, R), dim3(1024), lds, st, da);
-  else hipLaunchKernelGGL((k_attn_small<HD, GQ, 8>), dim3(g.nkv, R), dim3(512), lds, st, da);
+  const size_t lds = sizeof(float) * ((size_t)GQ * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + 2 * ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * HD);
+  hipLaunchKernelGGL((k_attn_small<HD, GQ, 8>), dim3(g.nkv, R), dim3(512), lds, st, da);
 }
 static bool attn_small_fits(const ixt_ctx* c, int R) {
   const AttnGeom& g = c->geom;
-  const size_t lds = sizeof(float) * ((size_t)c->GQ * c->D + (size_t)c->GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * c->D);
-  return c->small_attn_waves >= 8 && (long)R * c->KV <= c->small_attn_max_blocks && lds <= 64 * 1024 && (c->D == 128 || c->D == 64) && (c->GQ == 1 || c->GQ == 2 || c->GQ == 4);
+  const size_t lds = sizeof(float) * ((size_t)c->GQ * c->D + (size_t)c->GQ * ((g.Tmax + 3) & ~3) + 2 * ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * c->D);
+  return c->small_attn_waves >= 8 && (long)R * c->KV <= c->small_attn_max_blocks && lds <= 64 * 1024 && (c->D == 128 || c->D == 64) && (c->GQ == 1 || c->GQ == 2);   // (four query heads per kv head: the buffers spill)
 }
 static int launch_attn_small(ixt_ctx* c, int layer, int R, hipStream_t st) {
 #define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn_small_t<HD_, GQ_>(c, layer, R, st); LAUNCHCHK(); return IXT_OK; }
-  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+  ATT(128, 1) ATT(128, 2) ATT(64, 1) ATT(64, 2)
 #undef ATT
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
@@ -1304,7 +1305,12 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     GemmEpi e{};
     e.row_slot = c->row_slot; e.row_pos = c->row_pos; e.row_active = c->row_active; e.page_map = c->ps.page_map;
     e.rope_sin = c->rope_sin; e.rope_cos = c->rope_cos; e.qbuf = c->qbuf; e.kpages = c->kpages_l[l]; e.vpages = c->vpages_l[l]; e.g = c->geom;
-    TRY(launch_sdot(c, GEPI_QKV, true, hcur, w.ln1, w.wqkv, E, c->NQKV, R, e, st));
+    if (c->small_norm) {
+      TRY(launch_sdot(c, GEPI_QKV, true, hcur, w.ln1, w.wqkv, E, c->NQKV, R, e, st));
+    } else {
+      TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, w.ln1, c->xn, st));
+      TRY(launch_sdot(c, GEPI_QKV, false, c->xn, nullptr, w.wqkv, E, c->NQKV, R, e, st));
+    }
     {
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
       if (attn_small) {
@@ -1323,7 +1329,12 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     TRY(launch_sdot(c, GEPI_RESID, false, c->ao, nullptr, w.wo, c->QN, E, R, eo, st));
     GemmEpi eu{};
     eu.act = c->hact;
-    TRY(launch_sdot(c, GEPI_SWIGLU, true, hnext, w.ln2, w.wi, E, 2 * F, R, eu, st));
+    if (c->small_norm) {
+      TRY(launch_sdot(c, GEPI_SWIGLU, true, hnext, w.ln2, w.wi, E, 2 * F, R, eu, st));
+    } else {
+      TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hnext, nullptr, w.ln2, c->xn, st));
+      TRY(launch_sdot(c, GEPI_SWIGLU, false, c->xn, nullptr, w.wi, E, 2 * F, R, eu, st));
+    }
     if (down_small) {
       GemmEpi ed{};
       ed.h_in = hnext; ed.h_out = hcur;
@@ -1807,7 +1818,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;
@@ -1819,6 +1830,34 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
     return IXT_OK;
   }
   return set_err(IXT_ERR_INVALID, "unknown option %s", name);
+}
+
+// f2bf (hardware conversion) against the integer round-to-nearest-even formula over all 2^32 f32 bit patterns: the number of non-NaN
+// inputs on which they differ, plus the number of NaN inputs that do not stay NaN (tests/test_gpu_ops.py).
+__global__ __launch_bounds__(256) void k_cvt_check(unsigned long long* bad) {
+  unsigned long long n = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < (1ull << 32); i += (unsigned long long)gridDim.x * 256) {
+    const uint32_t u = (uint32_t)i;
+    const float f = __uint_as_float(u);
+    const bf16_t hw = f2bf(f), sw = f2bf_int(f);
+    const bool nan = (u & 0x7fffffffu) > 0x7f800000u;
+    if (nan ? ((hw & 0x7fffu) <= 0x7f80u) : (hw != sw)) ++n;
+  }
+  if (n) atomicAdd(bad, n);
+}
+extern "C" int ixt_op_cvt_check(ixt_ctx* c, int64_t* mismatches_out, void* stream) {
+  if (!c || !mismatches_out) return set_err(IXT_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  unsigned long long* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, sizeof(unsigned long long)));
+  HIPCHK(hipMemsetAsync(d, 0, sizeof(unsigned long long), st));
+  hipLaunchKernelGGL(k_cvt_check, dim3(4096), dim3(256), 0, st, d);
+  unsigned long long h = 0;
+  HIPCHK(hipMemcpyAsync(&h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  HIPCHK(hipFree(d));
+  *mismatches_out = (int64_t)h;
+  return IXT_OK;
 }
 
 extern "C" int ixt_timing_enable(ixt_ctx* c, int enable) {

@@ -1,7 +1,7 @@
 // ixt_small.h -- the decode step at FEW rows (one row block: R <= 16), five launches per layer (included by ixt_api.hip after ixt_gemm.h):
 //
 //   k_sdot<QKV, norm>     RMSNorm of the hidden rows (recomputed per block) -> QKV projection -> RoPE -> q buffer, K / V pages
-//   k_attn_small<NW>      one block of NW (16) waves per (row, kv head): scores, softmax statistics, PV, in-order super-block sums
+//   k_attn_small<NW>      one block of NW (8) waves per (row, kv head), page list in LDS, the whole K and V streams one round of loads each
 //   k_sdot<RESID>         output projection + residual
 //   k_sdot<SWIGLU, norm>  RMSNorm -> (wi_0, wi_1) projection -> SwiGLU
 //   k_sdot<RESID>         down projection + residual
@@ -42,9 +42,24 @@ __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
   const bool tile_ok = tile < ntile;
   const int r_in = lane & 15, cq = lane >> 4;
   f32x4* red = reinterpret_cast<f32x4*>(sx + ((size_t)nch << rpl));     // [chains][tpb][64]
-  float* blk = reinterpret_cast<float*>(red + (size_t)chains * tpb * 64);   // NORM: [R][nblk] block sums of squares
+  float* blk = reinterpret_cast<float*>(red + (size_t)chains * tpb * 64);   // NORM: [R][nblk] block sums of squares (R nblk <= 240), [240 + row] = 1 / sqrt(mean + eps)
+  u32x4* ssc = reinterpret_cast<u32x4*>(blk + 256);                         // NORM: the norm's scale, [K/8] pieces
 
-  // this wave's chain of weight fragments: everything in flight before anything else happens
+  // Round 0 of the activation loads goes out BEFORE the weight fragments: loads return in order, so the (L2-resident) activations can be
+  // waited for with the sixteen weight loads still in flight, and the whole prologue below runs under the weight stream.
+  // Piece p = (k-chunk p >> rpl, row p & (Rp - 1)); unconditional loads from clamped addresses (rows R .. Rp - 1 repeat row R - 1 / hold
+  // whatever the producer left in the fragment: never used).
+  const int np = nch << rpl;
+  auto xsrc = [&](int p) -> const u32x4* {
+    p = min(p, np - 1);
+    if constexpr (NORM) return reinterpret_cast<const u32x4*>(a.x + (size_t)min(p & (Rp - 1), R - 1) * K + (size_t)(p >> rpl) * 8);
+    else return reinterpret_cast<const u32x4*>(a.x) + (size_t)(p >> rpl) * 16 + (p & (Rp - 1));
+  };
+  u32x4 x0[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) x0[u] = *xsrc(tid + u * nthr);
+
+  // this wave's chain of weight fragments: all sixteen in flight
   const int s0 = c * 16, cs = min(16, nsteps - s0);
   const u32x4* wbase = a.w + ((size_t)(tile_ok ? tile : 0) * nsteps + s0) * 64 + lane;
   const bool full = tile_ok && cs == 16;      // the usual case: a whole chain, no per-step conditions anywhere
@@ -54,33 +69,55 @@ __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
 #pragma unroll
   for (int s = 0; s < 16; ++s) wv[s] = __builtin_nontemporal_load(wbase + (size_t)min(s, cs - 1) * 64);
 
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int p = tid + u * nthr;
+    if (p < np) sx[p] = x0[u];
+  }
+#pragma unroll 1
+  for (int p0 = tid + 8 * nthr; p0 < np; p0 += 4 * nthr) {   // more than 8 pieces per thread (many rows): further rounds of 4
+    u32x4 tmp[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tmp[u] = *xsrc(p0 + u * nthr);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * nthr;
+      if (p < np) sx[p] = tmp[u];
+    }
+  }
   if constexpr (NORM) {
     // RMSNorm (normalizations.py:57-70) in the canonical order of k_rownorm: chunk of 8 = one fma chain, block of 64 chunks by
-    // xor-butterfly, blocks added in order; y = bf16(x r), out = bf16(y scale).  A wave takes (row, block) pairs; lane = chunk.
+    // xor-butterfly, blocks added in order; y = bf16(x r), out = bf16(y scale).  Every block norms the rows for itself.
+    for (int i = tid; i < nch; i += nthr) ssc[i] = *reinterpret_cast<const u32x4*>(a.scale + i * 8);
+    __syncthreads();
+    // sums of squares from LDS: a wave takes (row, block) pairs, lane = chunk
     const int nblk = (nch + 63) >> 6, nw = nthr >> 6;
     for (int p = wave; p < R * nblk; p += nw) {
       const int row = p / nblk, b = p - row * nblk, ch = b * 64 + lane;
       float v = 0.0f;
       if (ch < nch) {
-        const u32x4 hv = *reinterpret_cast<const u32x4*>(a.x + (size_t)row * K + ch * 8);
+        const u32x4 hv = sx[((size_t)ch << rpl) + row];
         const float h[8] = {bflo(hv.x), bfhi(hv.x), bflo(hv.y), bfhi(hv.y), bflo(hv.z), bfhi(hv.z), bflo(hv.w), bfhi(hv.w)};
 #pragma unroll
         for (int j = 0; j < 8; ++j) v = __builtin_fmaf(h[j], h[j], v);
-        sx[((size_t)ch << rpl) + row] = hv;
       }
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) v = v + __shfl_xor(v, off, 64);
       if (lane == 0) blk[row * nblk + b] = v;
     }
     __syncthreads();
-    for (int p = tid; p < nch << rpl; p += nthr) {
+    if (tid < R) {                                   // 1 / sqrt(mean + eps) once per row
+      float total = 0.0f;
+      for (int b = 0; b < nblk; ++b) total = total + blk[tid * nblk + b];
+      blk[240 + tid] = 1.0f / sqrtf(total / (float)K + a.eps);
+    }
+    __syncthreads();
+    for (int p = tid; p < np; p += nthr) {           // normalise in place
       const int ch = p >> rpl, row = p & (Rp - 1);
       if (row < R) {
-        float total = 0.0f;
-        for (int b = 0; b < nblk; ++b) total = total + blk[row * nblk + b];
-        const float rs = 1.0f / sqrtf(total / (float)K + a.eps);
+        const float rs = blk[240 + row];
         const u32x4 hv = sx[p];
-        const u32x4 sv = *reinterpret_cast<const u32x4*>(a.scale + ch * 8);
+        const u32x4 sv = ssc[ch];
         const float h[8] = {bflo(hv.x), bfhi(hv.x), bflo(hv.y), bfhi(hv.y), bflo(hv.z), bfhi(hv.z), bflo(hv.w), bfhi(hv.w)};
         const float sc[8] = {bflo(sv.x), bfhi(sv.x), bflo(sv.y), bfhi(sv.y), bflo(sv.z), bfhi(sv.z), bflo(sv.w), bfhi(sv.w)};
         bf16_t o[8];
@@ -89,25 +126,6 @@ __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
         u32x4 ov;
         ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]); ov.z = pack2(o[4], o[5]); ov.w = pack2(o[6], o[7]);
         sx[p] = ov;
-      }
-    }
-  } else {
-    // rows 0 .. Rp - 1 of the activation fragments (rows R .. Rp - 1 are whatever the producer left there: never used), 4 pieces per
-    // thread and round, loads first; unconditional loads from clamped addresses keep the loop free of carried registers
-    const u32x4* xg = reinterpret_cast<const u32x4*>(a.x);
-    const int np = nch << rpl;
-#pragma unroll 1
-    for (int p0 = tid; p0 < np; p0 += 4 * nthr) {
-      u32x4 tmp[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = min(p0 + u * nthr, np - 1);
-        tmp[u] = xg[(size_t)(p >> rpl) * 16 + (p & (Rp - 1))];
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = p0 + u * nthr;
-        if (p < np) sx[p] = tmp[u];
       }
     }
   }
@@ -211,12 +229,16 @@ __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
 }
 
 // =====================================================================================================
-// Decode attention for few rows: k_attn_decode<HD, GQ, false> with NW waves per (row, kv head) block instead of four.  With R x nkv blocks
-// below the CU count a block is alone on its CU, and its time is the length of ITS serial chain: key tiles per wave, then the softmax, then
-// value groups per wave.  Sixteen waves cut the two streams to a quarter and put four times the bytes in flight per CU.  Same operation
-// order (scores: one fma chain over d; l: page sums in key order, pages in order; PV: page chains, 4 pages per super-block in order,
-// super-blocks in order).  q from qbuf, every key / value from the pages.  grid = (nkv, R), block 64 NW,
-// LDS = GQ HD + GQ Tmax' + mpg' + 16 + nsb_max HD floats.
+// Decode attention for few rows: the one-launch form (k_attn_decode<HD, GQ, false>) for blocks that are ALONE on their CU.  With R x nkv
+// blocks below the CU count a block's time is the length of ITS serial chain of memory round trips, so here
+//   * the row's page list sits in LDS before the first K load (k_attn_decode looks every page up in HBM in front of its loads: one more
+//     dependent round trip per tile and per V batch);
+//   * NW = 8 waves (not 4) share the key range, and every wave keeps up to TWO key tiles (4 half-tile buffers) and FOUR value batches
+//     in flight: at the benchmark's contexts (<= 40 pages of 32 keys) the whole K stream is one round of loads and the whole V stream
+//     another, issued before the softmax between them.
+// Same operation order (scores: one fma chain over d; l: page sums in key order, pages in order; PV: page chains, 4 pages per super-block
+// in order, super-blocks in order).  q from qbuf, every key / value from the pages.  grid = (nkv, R), block 64 NW,
+// LDS = GQ HD + GQ Tmax' + 2 mpg' + 16 + nsb_max HD floats.
 // =====================================================================================================
 template <int HD, int GQ, int NW>
 __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
@@ -234,35 +256,35 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
   float* qs = sm;                               // [GQ][HD]
   float* ebuf = qs + GQ * HD;                   // [GQ][Tmax'] scores -> exps -> P
   const int tp = (g.Tmax + 3) & ~3;
+  const int mpgp = (g.mpg + 3) & ~3;
   float* psum = ebuf + (size_t)GQ * tp;         // [mpg']
-  float* wred = psum + ((g.mpg + 3) & ~3);      // [16]
+  int32_t* pm = reinterpret_cast<int32_t*>(psum + mpgp);   // [mpg'] the row's page list
+  float* wred = reinterpret_cast<float*>(pm + mpgp);       // [16]
   float* sbs = wred + 16;                       // [nsb_max][HD]
   const int pos = a.row_pos[r];
   const int kv_len = pos + 1;
   const int pages = (kv_len + g.P - 1) / g.P;
   const int nsb = (pages + IXT_SB - 1) / IXT_SB;
   const int ppw = 64 / g.P;
-  const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
-
-  constexpr int KH = HD / 16;             // d-chunks per half tile
-  u32x4 ka[KH], kb[KH];
-#define IXT_KLOAD(DST_, F_)                                                                                       \
-  do {                                                                                                            \
-    const int ps_ = wave + NW * ((F_) >> 1), h_ = (F_) & 1;                                                       \
-    const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
-    if (ps_ * ppw < pages && j_ < kv_len) {                                                                       \
-      const bf16_t* kp_ = a.kpages + kpage_off(g, prow[pidx_], kvh, h_ * KH, lane % g.P);                         \
-      _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
-    }                                                                                                             \
-  } while (0)
-  IXT_KLOAD(ka, 0);
-  IXT_KLOAD(kb, 1);
   {
+    const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg;
+    for (int i = tid; i < pages; i += NT) pm[i] = prow[i];
     const bf16_t* qsrc = a.qbuf + ((size_t)r * g.nq + kvh * GQ) * HD;
     for (int i = tid; i < GQ * HD; i += NT) qs[i] = bf2f(qsrc[i]);
   }
   __syncthreads();
 
+  constexpr int KH = HD / 16;             // d-chunks per half tile
+  u32x4 k0[KH], k1[KH], k2[KH], k3[KH];   // half tiles f, f + 1 (one key tile) and f + 2, f + 3 (the next)
+#define IXT_KLOAD(DST_, F_)                                                                                       \
+  do {                                                                                                            \
+    const int ps_ = wave + NW * ((F_) >> 1), h_ = (F_) & 1;                                                       \
+    const int pidx_ = ps_ * ppw + lane / g.P, j_ = pidx_ * g.P + lane % g.P;                                      \
+    if (ps_ * ppw < pages && j_ < kv_len) {                                                                       \
+      const bf16_t* kp_ = a.kpages + kpage_off(g, pm[pidx_], kvh, h_ * KH, lane % g.P);                           \
+      _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
+    }                                                                                                             \
+  } while (0)
 #define IXT_KHALF(BUF_, F_)                                                                                       \
   do {                                                                                                            \
     const int ps_ = wave + NW * ((F_) >> 1), h_ = (F_) & 1;                                                       \
@@ -289,11 +311,16 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
   {
     const int ntile = (pages > wave * ppw) ? (pages - wave * ppw + NW * ppw - 1) / (NW * ppw) : 0;
     float acc[GQ];
-    for (int f = 0; f < 2 * ntile; f += 2) {
-      IXT_KHALF(ka, f);
-      IXT_KLOAD(ka, f + 2);
-      IXT_KHALF(kb, f + 1);
-      IXT_KLOAD(kb, f + 3);
+    IXT_KLOAD(k0, 0); IXT_KLOAD(k1, 1); IXT_KLOAD(k2, 2); IXT_KLOAD(k3, 3);
+    for (int f = 0; f < 2 * ntile; f += 4) {
+      IXT_KHALF(k0, f);
+      IXT_KHALF(k1, f + 1);
+      IXT_KLOAD(k0, f + 4); IXT_KLOAD(k1, f + 5);
+      if (f + 2 < 2 * ntile) {
+        IXT_KHALF(k2, f + 2);
+        IXT_KHALF(k3, f + 3);
+        IXT_KLOAD(k2, f + 6); IXT_KLOAD(k3, f + 7);
+      }
     }
   }
 #undef IXT_KHALF
@@ -312,7 +339,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
     if (f_ < nf) {                                                                                                \
       const int p_ = (wave + NW * (f_ / nb)) * PPW + tq, t0_ = (f_ % nb) * 8;                                     \
       if (p_ < pages) {                                                                                           \
-        const bf16_t* vp_ = a.vpages + vpage_off(g, prow[p_], kvh, t0_) + dc * 8;                                 \
+        const bf16_t* vp_ = a.vpages + vpage_off(g, pm[p_], kvh, t0_) + dc * 8;                                   \
         const int nt_ = min(g.P, kv_len - p_ * g.P) - t0_;                                                        \
         _Pragma("unroll") for (int u = 0; u < 8; ++u)                                                             \
           if (u < nt_) BUF_[u] = *reinterpret_cast<const u32x4*>(vp_ + (size_t)u * HD);                           \
@@ -353,9 +380,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
   } while (0)
   for (int q = 0; q < GQ; ++q) {
     float* e = ebuf + (size_t)q * tp;
-    u32x4 va[8], vb[8];
-    IXT_VLOAD(va, 0);
-    IXT_VLOAD(vb, 1);
+    u32x4 v0[8], v1[8], v2[8], v3[8];
+    IXT_VLOAD(v0, 0); IXT_VLOAD(v1, 1); IXT_VLOAD(v2, 2); IXT_VLOAD(v3, 3);
     float m = -INFINITY;
     for (int j = tid; j < kv_len; j += NT) m = fmaxf(m, e[j]);
 #pragma unroll
@@ -393,13 +419,12 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
     for (int j = tid; j < kv_len; j += NT) e[j] = rbf(e[j] / l);
     __syncthreads();
     float acc[8];
-    for (int f = 0; f < nf; f += 2) {
-      IXT_VBATCH(va, f);
-      IXT_VLOAD(va, f + 2);
-      if (f + 1 < nf) {
-        IXT_VBATCH(vb, f + 1);
-        IXT_VLOAD(vb, f + 3);
-      }
+    for (int f = 0; f < nf; f += 4) {
+      IXT_VBATCH(v0, f);
+      IXT_VLOAD(v0, f + 4);
+      if (f + 1 < nf) { IXT_VBATCH(v1, f + 1); IXT_VLOAD(v1, f + 5); }
+      if (f + 2 < nf) { IXT_VBATCH(v2, f + 2); IXT_VLOAD(v2, f + 6); }
+      if (f + 3 < nf) { IXT_VBATCH(v3, f + 3); IXT_VLOAD(v3, f + 7); }
     }
     __syncthreads();
     if (tid < HD) {

@@ -43,6 +43,15 @@ def _dot_case(ctx, x, w):
   assert bad.size == 0, f"{bad.size} of {R * N} outputs differ, first at {bad[:4]}: {got.ravel()[bad[:4]]} vs {ref.ravel()[bad[:4]]}"
 
 
+def test_bf16_conversion_exhaustive(ctx):
+  """Every kernel rounds f32 -> bf16 with the gfx950 conversion instruction; the oracle with the integer round-to-nearest-even formula.
+  All 2^32 inputs: equal on every non-NaN input (subnormals included), NaN stays NaN."""
+  torch, eng = ctx["torch"], ctx["eng"]
+  bad = ctypes.c_int64(-1)
+  H.lib.check(eng.lib.ixt_op_cvt_check(eng._ctx, ctypes.byref(bad), _st(torch)))
+  assert bad.value == 0
+
+
 # rows: 1..8 (one partly filled row block), 17/40/64 (2, 3->4, 4 row blocks sharing weights), 100 (two launches of row blocks);
 # K: single chain (<= 512), several chains, a short last chain (640, 1152)
 @pytest.mark.parametrize("R,K,N", [(1, 256, 512), (3, 128, 16), (8, 384, 528), (5, 1024, 1536), (17, 256, 1008), (2, 2048, 272),
