@@ -78,6 +78,11 @@ typedef struct ixt_config {
    * `post_self_attention_layer_norm/scale`.  Read for mixtral only (0 or 1 otherwise): */
   int32_t num_experts;             /* base.yml:160; <= 32 */
   int32_t num_experts_per_tok;     /* base.yml:161; <= min(num_experts, 8) */
+  /* Expert parallelism (moe.py:785-938: the experts of a layer split over the ranks of the `expert` mesh axis): this context keeps the
+   * kernels of experts [ep_rank E/ep_size, (ep_rank + 1) E/ep_size) only -- `MoeBlock_0/wi_0`, `wi_1`, `wo` are still handed over whole
+   * and the other experts' slices are skipped.  ep_size <= 1: every expert.  A sharded context serves ixt_op_moe_route / ixt_op_moe_experts
+   * (the two sides of the caller's exchange); the fused engine entry points need every expert and refuse. */
+  int32_t ep_rank, ep_size;
 } ixt_config;
 
 enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2, IXT_BLOCK_MIXTRAL = 3 };
@@ -221,6 +226,11 @@ int ixt_op_unembed_argmax(ixt_ctx* ctx, const uint16_t* y, int R, float* logits,
  * logits f32[rows][vocab] (the rounded logits ixt_prefill_chunk / ixt_generate / ixt_op_unembed_argmax write), chosen int32[rows] ->
  * out f32[rows] = log_softmax(logits[r])[chosen[r]]. */
 int ixt_op_logprob(ixt_ctx* ctx, const float* logits_dev, int rows, const int32_t* chosen_dev, float* out_dev, void* stream);
+/* Routed evaluation of THIS context's experts on rows that were sent here (moe.py:855-938 between the two all-to-alls; kernels/megablox/gmm.py:305):
+ * x bf16 [n][emb] row-major, expert_ids int32 [n] = the global expert of every row (device).  out bf16 [n][emb]: row i = expert_ids[i]'s MLP of
+ * x[i]; a row whose id is negative or belongs to another rank's experts is padding and comes back as zeros.  One launch sequence for all
+ * experts (rows are grouped by expert on the device, an expert without rows is never read); no host synchronisation. */
+int ixt_op_moe_experts(ixt_ctx* ctx, int layer, const uint16_t* x, const int32_t* expert_ids, int n, uint16_t* out, void* stream);
 /* Self-check of the f32 -> bf16 rounding every kernel uses (jax's astype(bfloat16): round to nearest even; the reference's dtype choice,
  * base.yml:86): the hardware conversion against the integer formula over all 2^32 inputs -> number of differing non-NaN inputs plus
  * NaN inputs that do not stay NaN (0 expected). */

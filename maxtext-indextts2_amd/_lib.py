@@ -35,6 +35,7 @@ class IxtConfig(ctypes.Structure):
       ("logits_via_embedding", ctypes.c_int32), ("normalize_embedding_logits", ctypes.c_int32),
       ("local_rope_max_timescale", ctypes.c_float), ("query_pre_attn_scalar", ctypes.c_float),
       ("num_experts", ctypes.c_int32), ("num_experts_per_tok", ctypes.c_int32),
+      ("ep_rank", ctypes.c_int32), ("ep_size", ctypes.c_int32),
   ]
 
 BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3, BLOCK_MIXTRAL = 0, 1, 2, 3
@@ -73,6 +74,7 @@ SIGNATURES = {
     "ixt_op_moe_route": (ctypes.c_int, [vp, ctypes.c_int, vp, ctypes.c_int, vp, vp, vp]),
     "ixt_op_moe_expert": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, vp, ctypes.c_int, vp, vp]),
     "ixt_op_moe_combine": (ctypes.c_int, [vp, vp, vp, ctypes.c_int, vp, vp]),
+    "ixt_op_moe_experts": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp]),
     "ixt_op_swiglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_geglu": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_op_residual": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int64, vp]),

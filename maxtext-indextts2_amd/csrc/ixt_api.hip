@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <map>
 #include <string>
 #include <vector>
@@ -84,7 +85,7 @@ struct ixt_ctx {
   AttnGeom geom{};
   // timing
   bool timing = false;
-  int attn_fused_min_blocks = 128;
+  int attn_fused_min_blocks = 64;    // (Mixtral-8x7B, 8 slots x 8 kv heads: one launch 19.5 ms per step against 20.5 for the split form)
   // tiled GEMM form of the dot: from 128 rows and 150 blocks of 128 x 128 (at C2 / 256 rows: the 2048 x 14336 MLP kernel only; the
   // 2048 x 6144 QKV kernel has 96 such blocks and measured slower than split-K, as did 64-column blocks)
   int gemm_min_rows = 128, gemm_min_blocks = 150;
@@ -112,9 +113,20 @@ struct ixt_ctx {
   bool gemma = false;
   bool moe = false;          // Mixtral (decoder_block == 3): the llama2 wiring with a routed mixture of NE expert MLPs, TK per row
   int NE = 1, TK = 1;
+  int NEL = 1, E0 = 0;       // expert parallelism: this context's experts are E0 .. E0 + NEL - 1 (ixt_config.ep_rank / ep_size)
   int32_t* moe_idx = nullptr;   // [Rmax][TK]
   float* moe_w = nullptr;       // [Rmax][TK]
   bf16_t* moe_y = nullptr;      // [Rmax][TK][E]
+  // routed evaluation (k_moe_plan / k_moe_gather, grouped k_dotb / k_gemm_ring): copies of a row sit in the rows of their expert
+  int moe_grouped = 1;          // 0: every expert over all rows (round 2's form; experiments)
+  int moe_rows_cap = 0;         // copy rows incl. alignment padding the workspaces hold
+  int32_t* moe_pos = nullptr;   // [Rmax TK] destination row of every copy
+  int32_t* moe_rbexp = nullptr; // [moe_rows_cap / 16] expert of every 16-row block, -1: none
+  int32_t* moe_cnt = nullptr;   // [2 NE] counts, offsets
+  bf16_t* moe_xg = nullptr;     // [moe_rows_cap][E] gathered inputs (xidx layout)
+  bf16_t* moe_hact = nullptr;   // [moe_rows_cap][F] SwiGLU outputs (xidx layout)
+  float* moe_comb = nullptr;    // [Rmax][E] the mixture as one f32 slice
+  size_t moe_wi_stride = 0, moe_wo_stride = 0;   // elements between two experts' kernels
   bool gemma3 = false;       // Gemma-3 (decoder_block == 2): gemma = true as well; one sub-layer per layer, layer l local unless l % 6 == 5
   float pv_cap = 0.0f;       // soft cap / window of the attention launch being issued (k_attn_pv)
   int pv_window = 0;
@@ -190,6 +202,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
               c.num_experts_per_tok > c.num_experts))
     return set_err(IXT_ERR_UNSUPPORTED, "mixtral: num_experts in [1, %d], num_experts_per_tok in [1, min(%d, num_experts)]", IXT_MOE_MAX_EXPERTS, IXT_MOE_MAX_TOPK);
   if (!moe && (c.num_experts > 1 || c.num_experts_per_tok > 1)) return set_err(IXT_ERR_UNSUPPORTED, "num_experts > 1 is built for decoder_block mixtral only");
+  if (c.ep_size > 1 && (!moe || c.ep_rank < 0 || c.ep_rank >= c.ep_size || c.num_experts % c.ep_size))
+    return set_err(IXT_ERR_INVALID, "expert parallelism: decoder_block mixtral, 0 <= ep_rank < ep_size, num_experts %% ep_size == 0");
   if (!gemma3 && (c.local_rope_max_timescale != 0.0f || c.query_pre_attn_scalar != 0.0f))
     return set_err(IXT_ERR_UNSUPPORTED, "local_rope_max_timescale and query_pre_attn_scalar are read for decoder_block gemma3 only");
   if (c.query_pre_attn_scalar < 0.0f) return set_err(IXT_ERR_INVALID, "negative query_pre_attn_scalar");
@@ -220,6 +234,8 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   x->cfg = c;
   x->E = c.emb_dim; x->Q = c.num_query_heads; x->KV = c.num_kv_heads; x->D = c.head_dim; x->F = c.mlp_dim;
   x->V = c.vocab_size; x->L = c.num_decoder_layers * ((gemma && !gemma3) ? 2 : 1); x->gemma = gemma; x->gemma3 = gemma3;
+  x->NEL = (moe && c.ep_size > 1) ? c.num_experts / c.ep_size : (moe ? c.num_experts : 1);
+  x->E0 = (moe && c.ep_size > 1) ? c.ep_rank * x->NEL : 0;
   x->moe = moe; x->NE = moe ? c.num_experts : 1; x->TK = moe ? c.num_experts_per_tok : 1; x->P = c.pagedattn_tokens_per_page; x->B = c.max_slots;
   x->QN = x->Q * x->D; x->KN = x->KV * x->D; x->NQKV = x->QN + 2 * x->KN; x->Tmax = c.max_target_length;
   x->mpg = c.pagedattn_max_pages_per_group; x->GQ = gq;
@@ -247,8 +263,13 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     A(dmalloc(x, &w.ln2, (size_t)E));
     if (moe) {
       A(dmalloc(x, &w.gate, (size_t)E * x->NE));
-      w.ewi.assign(x->NE, nullptr); w.ewout.assign(x->NE, nullptr);
-      for (int e = 0; e < x->NE; ++e) { A(dmalloc(x, &w.ewi[e], (size_t)E * 2 * F)); A(dmalloc(x, &w.ewout[e], (size_t)F * E)); }
+      // all experts' kernels of a layer in ONE allocation each, a fixed stride apart: the routed launches index them by expert on the device
+      w.ewi.assign(x->NEL, nullptr); w.ewout.assign(x->NEL, nullptr);
+      x->moe_wi_stride = (size_t)E * 2 * F; x->moe_wo_stride = (size_t)F * E;
+      bf16_t *wi_all = nullptr, *wo_all = nullptr;
+      A(dmalloc(x, &wi_all, x->moe_wi_stride * x->NEL));
+      A(dmalloc(x, &wo_all, x->moe_wo_stride * x->NEL));
+      for (int e = 0; e < x->NEL; ++e) { w.ewi[e] = wi_all + (size_t)e * x->moe_wi_stride; w.ewout[e] = wo_all + (size_t)e * x->moe_wo_stride; }
       w.wi = w.ewi[0]; w.wout = w.ewout[0];
     } else {
       A(dmalloc(x, &w.wi, (size_t)E * 2 * F));
@@ -263,6 +284,15 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     A(dmalloc(x, &x->moe_idx, (size_t)R * x->TK));
     A(dmalloc(x, &x->moe_w, (size_t)R * x->TK));
     A(dmalloc(x, &x->moe_y, (size_t)R * x->TK * E));
+    // copy rows: R TK copies, every expert's range padded to whole row groups of 128 rows (16 when there are at most 64 copies)
+    const int cap128 = (R * x->TK + 127) / 128 * 128 + 128 * x->NEL, cap16 = 64 + 16 * x->NEL;
+    x->moe_rows_cap = cap128 > cap16 ? cap128 : cap16;
+    A(dmalloc(x, &x->moe_pos, (size_t)R * x->TK));
+    A(dmalloc(x, &x->moe_rbexp, (size_t)x->moe_rows_cap / 16));
+    A(dmalloc(x, &x->moe_cnt, (size_t)2 * x->NEL));
+    A(dmalloc(x, &x->moe_xg, (size_t)x->moe_rows_cap * E));
+    A(dmalloc(x, &x->moe_hact, (size_t)x->moe_rows_cap * F));
+    A(dmalloc(x, &x->moe_comb, (size_t)R * E));
   }
   // RoPE tables
   host_rope_tables(c, c.rope_max_timescale, x->rope_sin_h, x->rope_cos_h);
@@ -321,6 +351,11 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     auto upd = [&](int K, int N) { size_t v = (size_t)((K + IXT_CHAIN - 1) / IXT_CHAIN) * N; if (v > gmaxn) gmaxn = v; };
     upd(E, x->NQKV); upd(x->QN, E); upd(E, 2 * F); upd(F, E);
     size_t split = gmaxn * (size_t)R;  // generous: any R may use SPLIT
+    if (moe) {   // routed experts: up to 64 + 16 NE copy rows on the split-K form, moe_rows_cap rows of one slice on the ring form
+      const size_t s16 = gmaxn * (size_t)(64 + 16 * x->NEL), s128 = (size_t)x->moe_rows_cap * E;
+      if (s16 > split) split = s16;
+      if (s128 > full) full = s128;
+    }
     x->part_floats = full > split ? full : split;
     A(dmalloc(x, &x->part, x->part_floats));
   }
@@ -466,13 +501,13 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
     if (rest == "MoeBlock_0/wi_0" || rest == "MoeBlock_0/wi_1") {
       const int which = rest == "MoeBlock_0/wi_1" ? 1 : 0;
       TRY(expect((int64_t)c->NE * E * F));
-      for (int e = 0; e < c->NE; ++e) TRY(tile_param(src + (size_t)e * E * F * esz, dtype, w.ewi[e], E, F, which, st, 2));
+      for (int e = 0; e < c->NEL; ++e) TRY(tile_param(src + (size_t)(c->E0 + e) * E * F * esz, dtype, w.ewi[e], E, F, which, st, 2));
       m |= 1u << (which ? W_WI1 : W_WI0);
       return IXT_OK;
     }
     if (rest == "MoeBlock_0/wo") {
       TRY(expect((int64_t)c->NE * F * E));
-      for (int e = 0; e < c->NE; ++e) TRY(tile_param(src + (size_t)e * F * E * esz, dtype, w.ewout[e], F, E, 0, st));
+      for (int e = 0; e < c->NEL; ++e) TRY(tile_param(src + (size_t)(c->E0 + e) * F * E * esz, dtype, w.ewout[e], F, E, 0, st));
       m |= 1u << W_WOUT;
       return IXT_OK;
     }
@@ -962,11 +997,12 @@ static int launch_attention(ixt_ctx* c, int layer, int R, int len_hint, const bf
 }
 
 static int launch_rownorm(ixt_ctx* c, int mode, int R, const int32_t* tokens, const DotResult* part, const bf16_t* h_in, bf16_t* h_out,
-                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st, int kmajor = 1, const int32_t* row_index = nullptr) {
+                          const bf16_t* scale, bf16_t* xn_out, hipStream_t st, int kmajor = 1, const int32_t* row_index = nullptr,
+                          const float* part_base = nullptr) {
   RowNormArgs a;
   a.xn_kmajor = kmajor;
   a.row_index = row_index;
-  a.tokens = tokens; a.embedding = c->embedding; a.part = c->part;
+  a.tokens = tokens; a.embedding = c->embedding; a.part = part_base ? part_base : c->part;
   a.slices = part ? part->slices : 0; a.slice_stride = part ? part->slice_stride : 0;
   a.h_in = h_in; a.h_out = h_out; a.scale = scale; a.xn_out = xn_out; a.E = c->E; a.eps = c->cfg.normalization_layer_epsilon;
   const size_t lds = sizeof(float) * ((size_t)c->E + 64);
@@ -1284,6 +1320,53 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
 //                       slice leaves the chip;
 //   fewer rows          split-K dots into f32 slices: dot_qkv, [front | qkv_finalize + scores], pv, combine, dot_o, rownorm (slice sum
 //                       + residual + norm), dot_wi, swiglu, dot_wo, rownorm (slice sum + residual + next norm).
+// Routed evaluation of a layer's experts (moe.py:785-938; megablox gmm.py:305): copy p = row p / top_k with expert idx[p] (expert ids relative to
+// `w`'s first resident expert).  x: rows in the dot kernels' x layout.  On return the down-projection of copy p is the sum over `res->slices`
+// slices of c->part row c->moe_pos[p] (rows of E floats, slice stride res->slice_stride).  An expert nobody chose is never read.
+//   at most 64 copies   split-K dots over 16-row blocks (decode: weight streaming), SwiGLU from the slices
+//   more                LDS-ring GEMMs over 128-row groups with the SwiGLU epilogue / one f32 slice
+static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, const int32_t* idx, int npairs, int top_k, hipStream_t st, DotResult* res) {
+  const int E = c->E, F = c->F;
+  const int align = npairs <= 64 ? 16 : 128;
+  const int rows_g = (npairs + align - 1) / align * align + align * c->NEL;
+  if (rows_g > c->moe_rows_cap) return set_err(IXT_ERR_INVALID, "moe: %d copies exceed the routed workspaces (%d rows)", npairs, c->moe_rows_cap);
+  hipLaunchKernelGGL(k_moe_plan, dim3(1), dim3(1024), 0, st, idx, npairs, c->E0, c->NEL, align, rows_g / 16, c->moe_pos, c->moe_rbexp, c->moe_cnt);
+  hipLaunchKernelGGL(k_moe_gather, dim3((E + 2047) / 2048, npairs), dim3(256), 0, st, x, c->moe_pos, top_k, E, c->moe_xg);
+  LAUNCHCHK();
+  const size_t wi_stride = c->moe_wi_stride / 8, wo_stride = c->moe_wo_stride / 8;   // 16-byte units
+  if (align == 16) {
+    const int zblocks = rows_g / 16;
+    auto dotg = [&](const bf16_t* xin, const bf16_t* wbase, size_t wstride, int K, int N) -> int {
+      const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN, nwaves = N / 16;
+      if ((size_t)chains * rows_g * N > c->part_floats) return set_err(IXT_ERR_INVALID, "moe: slice workspace too small");
+      const int ti = timing_begin(c, st, (double)K * N * 2.0 * c->NEL + (double)rows_g * K * 2.0 + (double)chains * rows_g * N * 4.0);
+      dim3 grid((((nwaves + 3) / 4 + 7) / 8) * 8 * zblocks, chains, 1);
+      hipLaunchKernelGGL((k_dotb<1, true, true>), grid, dim3(256), (size_t)16 * 1024, st, reinterpret_cast<const u32x4*>(xin), reinterpret_cast<const u32x4*>(wbase), K, N,
+                         rows_g, c->part, nwaves, zblocks, c->moe_rbexp, wstride);
+      timing_end(c, st, ti);
+      LAUNCHCHK();
+      return chains;
+    };
+    int ch = dotg(c->moe_xg, w.ewi[0], wi_stride, E, 2 * F);
+    if (ch < 0) return ch;
+    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, rows_g), dim3(256), 0, st, c->part, ch, (size_t)rows_g * 2 * F, F, c->moe_hact, c->moe_rbexp);
+    LAUNCHCHK();
+    ch = dotg(c->moe_hact, w.ewout[0], wo_stride, F, E);
+    if (ch < 0) return ch;
+    res->slices = ch; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
+    return IXT_OK;
+  }
+  if ((size_t)rows_g * E > c->part_floats) return set_err(IXT_ERR_INVALID, "moe: output workspace too small");
+  GemmEpi eu{};
+  eu.act = c->moe_hact; eu.rb_exp = c->moe_rbexp; eu.wstride = wi_stride;
+  TRY(launch_ring(c, GEPI_SWIGLU, c->moe_xg, w.ewi[0], E, 2 * F, rows_g, eu, false, st));
+  GemmEpi ed{};
+  ed.out = c->part; ed.rb_exp = c->moe_rbexp; ed.wstride = wo_stride;
+  TRY(launch_ring(c, GEPI_F32, c->moe_hact, w.ewout[0], F, E, rows_g, ed, false, st));
+  res->slices = 1; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
+  return IXT_OK;
+}
+
 // Few rows (R <= 16, llama2 block): five launches per layer, nothing but K / V pages, q, the attention output and the hidden rows leaves the chip
 // between them (ixt_small.h).  Same results as the other forms bit for bit (tests/test_gpu_small.py compares the two paths of one engine).
 static bool small_path_ok(const ixt_ctx* c, int R) {
@@ -1359,6 +1442,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
   if (c->gemma) return forward_rows_gemma2(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, st);
+  if (c->moe && c->NEL != c->NE) return set_err(IXT_ERR_UNSUPPORTED, "this context holds experts %d..%d of %d: the fused engine needs every expert (expert-parallel contexts serve ixt_op_moe_route / ixt_op_moe_experts)", c->E0, c->E0 + c->NEL - 1, c->NE);
   if (small_path_ok(c, R)) return forward_rows_small(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, decode, st);
   const int E = c->E, F = c->F;
   DotResult dr;
@@ -1448,8 +1532,22 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       // output does not depend on which other rows share its launch, so this equals the routed (permute / gmm / unpermute) form bit for
       // bit; it reads each expert's kernels once per pass, which is what decode with >= ~16 rows needs anyway, and spends
       // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
-      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(256), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
+      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
       LAUNCHCHK();
+      if (c->moe_grouped) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
+        DotResult mr;
+        TRY(moe_experts_routed(c, w, c->xn, c->moe_idx, R * c->TK, c->TK, st, &mr));
+        hipLaunchKernelGGL(k_moe_combine_rows, dim3((E + 255) / 256, R), dim3(256), 0, st, c->part, mr.slices, mr.slice_stride, c->moe_pos, c->moe_w, E, c->TK, c->moe_comb);
+        LAUNCHCHK();
+        dr.slices = 1; dr.slice_stride = (size_t)R * E;
+        if (next_scale != nullptr) {
+          TRY(launch_rownorm(c, 1, R, nullptr, &dr, hnext, hcur, next_scale, c->xn, st, 1, nullptr, c->moe_comb));
+        } else {
+          hipLaunchKernelGGL(k_sumres, dim3((E + 255) / 256, R), dim3(128), 0, st, c->moe_comb, dr.slices, dr.slice_stride, hnext, hcur, E);
+          LAUNCHCHK();
+        }
+        continue;
+      }
       for (int e = 0; e < c->NE; ++e) {
         TRY(launch_dot(c, c->xn, w.ewi[e], E, 2 * F, R, c->part, c->part_floats, false, st, &dr));
         hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, R), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, F, c->hact);
@@ -1674,7 +1772,7 @@ extern "C" int ixt_op_moe_route(ixt_ctx* c, int layer, const uint16_t* x, int R,
   if (!x || !experts_out || !weights_out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   TRY(transpose_rows(c, x, R, c->E, st));
-  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(256), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
+  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -1682,7 +1780,8 @@ extern "C" int ixt_op_moe_route(ixt_ctx* c, int layer, const uint16_t* x, int R,
 extern "C" int ixt_op_moe_expert(ixt_ctx* c, int layer, int expert, const uint16_t* x, int R, uint16_t* out, void* stream) {
   TRY(check_moe_layer(c, layer));
   if (!x || !out || R <= 0 || R > c->Rmax) return set_err(IXT_ERR_INVALID, "bad argument (rows in (0, %d])", c->Rmax);
-  if (expert < 0 || expert >= c->NE) return set_err(IXT_ERR_RANGE, "expert %d out of range [0, %d)", expert, c->NE);
+  if (expert < c->E0 || expert >= c->E0 + c->NEL) return set_err(IXT_ERR_RANGE, "expert %d is not one of this context's experts [%d, %d)", expert, c->E0, c->E0 + c->NEL);
+  expert -= c->E0;
   hipStream_t st = (hipStream_t)stream;
   const int E = c->E, F = c->F;
   const LayerW& w = c->layers[layer];
@@ -1695,6 +1794,22 @@ extern "C" int ixt_op_moe_expert(ixt_ctx* c, int layer, int expert, const uint16
   const size_t n = (size_t)R * E;
   hipLaunchKernelGGL(k_slices_to_bf16, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, n, out);
   LAUNCHCHK();
+  return IXT_OK;
+}
+
+extern "C" int ixt_op_moe_experts(ixt_ctx* c, int layer, const uint16_t* x, const int32_t* expert_ids, int n, uint16_t* out, void* stream) {
+  TRY(check_moe_layer(c, layer));
+  if (!x || !expert_ids || !out || n <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipStream_t st = (hipStream_t)stream;
+  // the workspaces hold Rmax rows: more rows (the receive side of an exchange holds ranks x capacity of them, mostly padding) go through in pieces
+  for (int r0 = 0; r0 < n; r0 += c->Rmax) {
+    const int m = std::min(c->Rmax, n - r0);
+    TRY(transpose_rows(c, x + (size_t)r0 * c->E, m, c->E, st));
+    DotResult mr;
+    TRY(moe_experts_routed(c, c->layers[layer], c->xt_op, expert_ids + r0, m, 1, st, &mr));
+    hipLaunchKernelGGL(k_moe_rows_out, dim3((c->E + 255) / 256, m), dim3(256), 0, st, c->part, mr.slices, mr.slice_stride, c->moe_pos, c->E, out + (size_t)r0 * c->E);
+    LAUNCHCHK();
+  }
   return IXT_OK;
 }
 
@@ -1818,7 +1933,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"moe_grouped", &c->moe_grouped, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

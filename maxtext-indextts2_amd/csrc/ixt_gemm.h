@@ -38,6 +38,7 @@ struct GemmEpi {
   const bf16_t* rope_sin; const bf16_t* rope_cos;
   bf16_t* qbuf; bf16_t* kpages; bf16_t* vpages;
   AttnGeom g;
+  const int32_t* rb_exp; size_t wstride;                // routed experts: expert of every 16-row block (-1: none), 16-byte units between experts' kernels
 };
 
 template <int N_>
@@ -65,6 +66,11 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
   const int bx = blockIdx.x;
   const int colg = (bx / (8 * zb)) * 8 + (bx & 7), rowg = (bx >> 3) % zb;
   if (colg >= ncolg) return;                                    // whole block: no barrier is skipped
+  if (e.rb_exp != nullptr) {                                    // routed experts (k_moe_plan, align 128): this row group's expert, or nothing to do
+    const int ex = (rowg * (WR * RB) < ((R + 15) >> 4)) ? e.rb_exp[rowg * (WR * RB)] : -1;
+    if (ex < 0) return;
+    wt += (size_t)ex * e.wstride;
+  }
   const int nsteps = K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;
   const int nchunks = nsteps / KS;
   const int wr = wave / WC, wc = wave % WC;

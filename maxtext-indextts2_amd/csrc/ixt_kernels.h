@@ -82,9 +82,12 @@ __host__ __device__ __forceinline__ int qk_col(int i, int half) {
 //   fragments from LDS.  Without the LDS copy every wave pulls the whole slab through L2 itself: 4x the weight bytes at 64 rows.
 //   SPLIT (one chain per block, 256 threads): the slab loads are issued BEFORE the weight loads -- loads return in order, so
 //   the L2-resident slab lands and is written to LDS while the weight fragments are still on their way from HBM.
+//   Routed experts (rb_exp != nullptr; NRB = 1): row block rb belongs to expert rb_exp[rb], whose kernels start wstride 16-byte units after
+//   wt; a row block of no expert (-1) leaves at once (k_moe_plan, ixt_moe_kernels.h).
 template <int NRB, bool SPLIT, bool NT>
 __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
-                                                 float* __restrict__ out, int nwaves, int zblocks) {
+                                                 float* __restrict__ out, int nwaves, int zblocks, const int32_t* __restrict__ rb_exp = nullptr,
+                                                 size_t wstride = 0) {
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][16 steps][64 lanes]
   const int tid = threadIdx.x, nthr = blockDim.x, wpb = nthr >> 6;
   const int wave = tid >> 6, lane = tid & 63;
@@ -100,6 +103,11 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
   const int r_in = lane & 15, cq = lane >> 4;
   const bool tile_ok = tile < nwaves;
   const u32x4* wbase = wt + (size_t)(tile_ok ? tile : 0) * nsteps * 64 + lane;
+  if (rb_exp != nullptr) {
+    const int ex = rb_exp[rb0];
+    if (ex < 0) return;                                  // the whole block: no barrier is skipped
+    wbase += (size_t)ex * wstride;
+  }
   f32x4 tot[NRB];
 #pragma unroll
   for (int b = 0; b < NRB; ++b) tot[b] = f32x4(0.0f);
@@ -658,9 +666,10 @@ __global__ __launch_bounds__(256) void k_rownorm(RowNormArgs a) {
 // 16-byte store: 8 consecutive features of a row are one lane's fragment bytes in the dot kernel's x layout).
 // =====================================================================================================
 __global__ __launch_bounds__(256) void k_swiglu_part(const float* part, int slices, size_t slice_stride, int F,
-                                                      bf16_t* out /*[R][F] in xidx layout*/) {
+                                                      bf16_t* out /*[R][F] in xidx layout*/, const int32_t* rb_exp = nullptr) {
   const int f0 = (blockIdx.x * 256 + threadIdx.x) * 8, r = blockIdx.y;
   if (f0 >= F) return;
+  if (rb_exp != nullptr && rb_exp[r >> 4] < 0) return;      // routed experts: a row block nobody's copies live in
   const float* p = part + (size_t)r * 2 * F;
   float a[8], b[8];
 #pragma unroll

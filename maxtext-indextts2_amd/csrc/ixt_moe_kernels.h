@@ -9,26 +9,41 @@
 #define IXT_MOE_MAX_EXPERTS 32
 #define IXT_MOE_MAX_TOPK 8
 
-// grid = R, block = 256 (4 waves, each takes every fourth expert's logit).  xn: the dot kernels' x layout (xidx); gate: row-major bf16 [E][n_exp].
-__global__ __launch_bounds__(256) void k_moe_route(const bf16_t* xn, const bf16_t* gate, int E, int n_exp, int top_k, int32_t* idx_out /*[R][top_k]*/,
-                                                  float* w_out /*[R][top_k]*/) {
+// grid = R, block = 64 n_exp (one wave per expert: the n_exp dot products of a row run side by side, each wave's loads of a block of 512 k
+// issued together).  xn: the dot kernels' x layout (xidx); gate: row-major bf16 [E][n_exp].
+__global__ __launch_bounds__(1024) void k_moe_route(const bf16_t* xn, const bf16_t* gate, int E, int n_exp, int top_k, int32_t* idx_out /*[R][top_k]*/,
+                                                   float* w_out /*[R][top_k]*/) {
   __shared__ float gl[IXT_MOE_MAX_EXPERTS];
-  const int r = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = blockIdx.x, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nch = E / 8, nblk = (nch + 63) / 64;
-  for (int e = wave; e < n_exp; e += 4) {
+  for (int e = wave; e < n_exp; e += nw) {
     float total = 0.0f;
-    for (int b = 0; b < nblk; ++b) {
-      const int ch = b * 64 + lane;
-      float a = 0.0f;
-      if (ch < nch) {
-        const u32x4 xv = *reinterpret_cast<const u32x4*>(xn + xidx(r, ch * 8, E));
-        const float x[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+    for (int b0 = 0; b0 < nblk; b0 += 4) {                 // four blocks of 512 k per round: 4 activation and 32 gate loads in flight per lane
+      u32x4 xv[4];
+      bf16_t gv[4][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) a = __builtin_fmaf(x[j], bf2f(gate[(size_t)(ch * 8 + j) * n_exp + e]), a);
+      for (int u = 0; u < 4; ++u) {
+        const int ch = min((b0 + u) * 64 + lane, nch - 1);
+        xv[u] = *reinterpret_cast<const u32x4*>(xn + xidx(r, ch * 8, E));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gv[u][j] = gate[(size_t)(ch * 8 + j) * n_exp + e];
       }
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) a = a + __shfl_xor(a, off, 64);
-      total = total + a;
+      for (int u = 0; u < 4; ++u) {
+        if (b0 + u < nblk) {
+          const int ch = (b0 + u) * 64 + lane;
+          float a = 0.0f;
+          if (ch < nch) {
+            const float x[8] = {bflo(xv[u].x), bfhi(xv[u].x), bflo(xv[u].y), bfhi(xv[u].y), bflo(xv[u].z), bfhi(xv[u].z), bflo(xv[u].w), bfhi(xv[u].w)};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a = __builtin_fmaf(x[j], bf2f(gv[u][j]), a);
+          }
+#pragma unroll
+          for (int off = 1; off < 64; off <<= 1) a = a + __shfl_xor(a, off, 64);
+          total = total + a;
+        }
+      }
     }
     if (lane == 0) gl[e] = rbf(total);
   }
@@ -76,4 +91,83 @@ __global__ __launch_bounds__(256) void k_slices_to_bf16(const float* part, int s
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   out[i] = f2bf(sum_slices<16>(part + i, slice_stride, slices));
+}
+
+// =====================================================================================================
+// Routed ("grouped") evaluation of the experts (layers/moe.py:420-453 `permute`, :785-938 sparse_matmul; kernels/megablox/gmm.py:305): every
+// (row, j) copy goes to the rows of ITS expert and each expert's kernels run over its own rows only.
+//   k_moe_plan    pair p = r top_k + j of expert e gets destination row pos[p] = off[e] + (number of earlier pairs of e): the stable order of the
+//                 reference's argsort.  off[e] is aligned to `align` rows (16: one row block of the dot kernels; 128: one row group of the ring
+//                 GEMM), so no row block holds copies of two experts, and rb_exp[row block] = its expert (-1: nothing there -- the GEMM block
+//                 leaves at once, the expert's kernels are not read).  One block of 1024 threads.
+//   k_moe_gather  xg[pos[p]] = xn[r] in the dot kernels' x layout.
+// The order of the copies inside an expert changes nothing: a row's result does not depend on its neighbours in a launch.
+// =====================================================================================================
+__global__ __launch_bounds__(1024) void k_moe_plan(const int32_t* idx /*[npairs]*/, int npairs, int e0, int n_exp, int align, int nrb_cap, int32_t* pos /*[npairs]*/,
+                                                   int32_t* rb_exp /*[nrb_cap]*/, int32_t* cnt_off /*[2 n_exp]: counts, then offsets*/) {
+  __shared__ int wsum[16];
+  __shared__ int s_base, s_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nrb_cap; i += 1024) rb_exp[i] = -1;
+  for (int i = tid; i < npairs; i += 1024) pos[i] = -1;     // a copy of no resident expert (expert-parallel padding) stays without a row
+  if (tid == 0) s_off = 0;
+  __syncthreads();
+  for (int e = 0; e < n_exp; ++e) {
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    const int off = s_off;
+    for (int p0 = 0; p0 < npairs; p0 += 1024) {
+      const int p = p0 + tid;
+      const bool mine = p < npairs && idx[p] - e0 == e;
+      const unsigned long long bal = __ballot(mine);
+      const int before = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) wsum[wave] = __popcll(bal);
+      __syncthreads();
+      int wbefore = 0, total = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) { const int v = wsum[w]; if (w < wave) wbefore += v; total += v; }
+      const int base = s_base;
+      if (mine) pos[p] = off + base + wbefore + before;
+      __syncthreads();
+      if (tid == 0) s_base = base + total;
+      __syncthreads();
+    }
+    const int n = s_base;
+    const int nrb = (n + 15) >> 4;
+    for (int i = tid; i < nrb; i += 1024) rb_exp[(off >> 4) + i] = e;
+    if (tid == 0) {
+      cnt_off[e] = n;
+      cnt_off[n_exp + e] = off;
+      s_off = off + ((n + align - 1) / align) * align;
+    }
+    __syncthreads();
+  }
+}
+
+// grid = (ceil(E / 2048), npairs), block 256: 8 consecutive features per thread.
+__global__ __launch_bounds__(256) void k_moe_gather(const bf16_t* xn /*xidx, [R][E]*/, const int32_t* pos, int top_k, int E, bf16_t* xg /*xidx*/) {
+  const int k0 = (blockIdx.x * 256 + threadIdx.x) * 8, p = blockIdx.y;
+  if (k0 >= E || pos[p] < 0) return;
+  *reinterpret_cast<u32x4*>(xg + xidx(pos[p], k0, E)) = *reinterpret_cast<const u32x4*>(xn + xidx(p / top_k, k0, E));
+}
+
+// The mixture from the experts' down-projection slices in copy-row order: y_j = bf16(sum of slices of row pos[r top_k + j]),
+// out[r][c] = bf16(fma chain over j of y_j weight_j) as one f32 slice (k_moe_combine's arithmetic).  grid = ((E + 255) / 256, R), block 256.
+__global__ __launch_bounds__(256) void k_moe_combine_rows(const float* part, int slices, size_t slice_stride, const int32_t* pos, const float* w, int E, int top_k,
+                                                          float* out /*[R][E]*/) {
+  const int c = blockIdx.x * 256 + threadIdx.x, r = blockIdx.y;
+  if (c >= E) return;
+  float t = 0.0f;
+  for (int j = 0; j < top_k; ++j) {
+    const float y = rbf(sum_slices<16>(part + (size_t)pos[(size_t)r * top_k + j] * E + c, slice_stride, slices));
+    t = __builtin_fmaf(y, w[(size_t)r * top_k + j], t);
+  }
+  out[(size_t)r * E + c] = rbf(t);
+}
+
+// op-level form of the routed evaluation (ixt_op_moe_experts): out[p] = bf16(sum of slices of row pos[p]).  grid = ((E + 255) / 256, npairs).
+__global__ __launch_bounds__(256) void k_moe_rows_out(const float* part, int slices, size_t slice_stride, const int32_t* pos, int E, bf16_t* out /*[npairs][E]*/) {
+  const int c = blockIdx.x * 256 + threadIdx.x, p = blockIdx.y;
+  if (c >= E) return;
+  out[(size_t)p * E + c] = pos[p] < 0 ? (bf16_t)0 : f2bf(sum_slices<16>(part + (size_t)pos[p] * E + c, slice_stride, slices));
 }

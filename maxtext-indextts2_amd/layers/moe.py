@@ -36,8 +36,9 @@ class RoutedMoE:
     shape = inputs.shape
     x = inputs.reshape(-1, shape[-1]).contiguous()
     experts, weights = self.ctx.moe_route(self.layer, x)
-    y = moe_ep.expert_parallel_apply(x, experts.to(torch.int64), self.num_experts, lambda e, rows: self.ctx.moe_expert(self.layer, e, rows.contiguous()),
-                                     always_exchange=self.always_exchange)
+    # dropless fixed-capacity exchange around ONE routed launch sequence for this rank's experts: no host synchronisation, no Python loop
+    y = moe_ep.expert_parallel_apply_grouped(x, experts.to(torch.int64), self.num_experts, lambda rows, ids: self.ctx.moe_experts(self.layer, rows.contiguous(), ids),
+                                             always_exchange=self.always_exchange)
     return self.ctx.moe_combine(y.contiguous(), weights).reshape(shape), None
 
 

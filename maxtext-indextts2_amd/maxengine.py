@@ -114,6 +114,7 @@ class MaxEngine(engine_api.Engine):
     elif config.decoder_block == "mixtral":            # layers/mixtral.py:52-170, layers/moe.py
       c.decoder_block = _lib.BLOCK_MIXTRAL
       c.num_experts, c.num_experts_per_tok = int(config.num_experts), int(config.num_experts_per_tok)
+      c.ep_rank, c.ep_size = int(config.ixt_expert_parallel_rank), int(config.ixt_expert_parallel_size)
     self._staging = int(config.ixt_staging_groups)
     self._packed_rows = max(int(config.ixt_max_packed_rows), int(config.max_prefill_predict_length))
     self._ccfg = c

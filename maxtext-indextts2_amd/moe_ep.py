@@ -122,6 +122,59 @@ def expert_parallel_apply(x: torch.Tensor, selected_experts: torch.Tensor, num_e
   return y.reshape(R, K, x.shape[1])
 
 
+def expert_parallel_apply_grouped(x: torch.Tensor, selected_experts: torch.Tensor, num_experts: int,
+                                  experts_fn: Callable[[torch.Tensor, torch.Tensor], torch.Tensor], group=None, always_exchange: bool = False,
+                                  capacity: int | None = None) -> torch.Tensor:
+  """The hot-path form of `expert_parallel_apply`: same result, NO host synchronisation (no size exchange, no `.tolist()`, no tensor whose
+  shape depends on the routing) and no per-expert Python loop.
+
+  x [rows, emb], selected_experts int [rows, k] of THIS rank -> y [rows, k, emb].  `experts_fn(rows_x [n, emb], ids int32 [n]) -> [n, emb]` evaluates
+  the local experts on packed rows in one call (on a GPU: OpContext.moe_experts = ixt_op_moe_experts); ids < 0 mark padding rows whose result
+  is not read.  The exchange has a FIXED capacity: every rank sends `capacity` rows to every rank, so both all-to-alls have equal splits known
+  without looking at the routing; the expert ids travel with the rows.  `capacity` must be the same on every rank; the default, rows * k, is
+  dropless (the most one destination can receive from this rank) and needs the same number of rows on every rank (decode: max_slots).  A
+  smaller capacity drops the copies beyond it -- their y rows are zero, as with the reference's capacity_factor (moe.py:1120-1190).  On the
+  fully connected xGMI node the all-to-all gives each of a GPU's 7 links its own slice; the price of not synchronising is the padding
+  (decode: rows * k <= a few dozen rows of emb bf16 per peer and layer)."""
+  exchange = dist.is_initialized() and (dist.get_world_size(group) > 1 or always_exchange)
+  world = dist.get_world_size(group) if exchange else 1
+  if num_experts % world:
+    raise ValueError(f"num_experts ({num_experts}) must be a multiple of the expert-parallel degree ({world})")
+  per_rank = num_experts // world
+  R, K = selected_experts.shape
+  emb = x.shape[1]
+  cap = int(capacity) if capacity is not None else R * K
+  flat = selected_experts.reshape(-1).to(torch.int64)
+  dest = torch.div(flat, per_rank, rounding_mode="floor")                              # owning rank of every copy
+  # slot of a copy inside its destination's buffer = number of earlier copies with the same destination (stable, as the reference's sort)
+  onehot = torch.nn.functional.one_hot(dest, world)
+  slot = (torch.cumsum(onehot, dim=0) - onehot).gather(1, dest[:, None])[:, 0]
+  keep = slot < cap
+  trash = world * cap                                                                  # one extra row takes what does not fit
+  lin = torch.where(keep, dest * cap + slot, torch.full_like(slot, trash))
+  src_rows = torch.div(torch.arange(R * K, device=x.device), K, rounding_mode="floor")
+  send_x = x.new_zeros((trash + 1, emb))
+  send_id = torch.full((trash + 1,), -1, dtype=torch.int32, device=x.device)
+  send_x.index_copy_(0, lin, x.index_select(0, src_rows))
+  send_id.index_copy_(0, lin, flat.to(torch.int32))
+  send_x, send_id = send_x[:trash], send_id[:trash].contiguous()
+  if exchange:
+    recv_x, recv_id = torch.empty_like(send_x), torch.empty_like(send_id)
+    dist.all_to_all_single(recv_x, send_x, group=group)                                # equal splits: `cap` rows per peer
+    dist.all_to_all_single(recv_id, send_id, group=group)
+  else:
+    recv_x, recv_id = send_x, send_id
+  recv_y = experts_fn(recv_x, recv_id)
+  if exchange:
+    back = torch.empty_like(recv_y)
+    dist.all_to_all_single(back, recv_y, group=group)
+  else:
+    back = recv_y
+  y = back.index_select(0, torch.where(keep, lin, torch.zeros_like(lin)))
+  y = torch.where(keep[:, None], y, torch.zeros_like(y))
+  return y.reshape(R, K, emb)
+
+
 def combine(y: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
   """moe.py:467-484 `unpermute`: einsum("BKE,BK -> BE") in f32 over the k copies in top_k order, as one fma chain (the canonical order of
   the single-GPU kernel k_moe_combine); result in y's dtype."""

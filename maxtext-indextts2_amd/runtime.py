@@ -76,6 +76,14 @@ class OpContext:
     _lib.check(self.lib.ixt_op_moe_expert(self.ctx, layer, int(expert), _vp(x), x.shape[0], _vp(out), _stream()))
     return out
 
+  def moe_experts(self, layer: int, x: torch.Tensor, expert_ids: torch.Tensor) -> torch.Tensor:
+    """Routed evaluation of this context's experts: x bf16 [n, emb], expert_ids int32 [n] (global ids; negative or another rank's: padding ->
+    a zero row).  One launch sequence for all experts, no host synchronisation."""
+    out = torch.empty_like(x)
+    ids = expert_ids.to(torch.int32).contiguous()
+    _lib.check(self.lib.ixt_op_moe_experts(self.ctx, layer, _vp(x), _vp(ids), x.shape[0], _vp(out), _stream()))
+    return out
+
   def moe_combine(self, y: torch.Tensor, weights: torch.Tensor) -> torch.Tensor:
     out = torch.empty((y.shape[0], y.shape[2]), dtype=y.dtype, device=y.device)
     _lib.check(self.lib.ixt_op_moe_combine(self.ctx, _vp(y), _vp(weights), y.shape[0], _vp(out), _stream()))

@@ -160,3 +160,59 @@ def test_mixtral_transformer_from_modules_expert_parallel_path():
     if started:
       dist.destroy_process_group()
     runtime._default = saved
+
+
+def test_expert_sharded_contexts_cover_the_mixture():
+  """Expert parallelism below Python: two contexts that each keep HALF of the experts' kernels in HBM (ixt_config.ep_rank / ep_size) evaluate,
+  with ixt_op_moe_experts, only the rows of their own experts (other rows come back as zeros: what the fixed-capacity exchange pads with);
+  together they give every (row, k) copy exactly the oracle's per-expert output, and the mixture assembled from them equals orc_moe_rows bit
+  for bit.  The fused engine entry points of a sharded context refuse."""
+  import ctypes
+  import importlib
+  import torch
+  from oracle import oracle as O
+  runtime = importlib.import_module("maxtext-indextts2_amd.runtime")
+  cfg = _cfg(max_prefill_predict_length=64)
+  w = H.synth.synth_weights(cfg, 14)
+  orc = H.make_oracle(cfg, w)
+  full_eng, _ = H.make_engine(cfg, w)
+  full = runtime.OpContext(engine=full_eng)
+  NE, TK, E = int(cfg.num_experts), int(cfg.num_experts_per_tok), cfg.emb_dim
+  shards = []
+  for rank in range(2):
+    c = _cfg(max_prefill_predict_length=64, ixt_expert_parallel_rank=rank, ixt_expert_parallel_size=2)
+    eng, _ = H.make_engine(c, w)
+    shards.append((eng, runtime.OpContext(engine=eng)))
+  rng = np.random.default_rng(5)
+  R = 29
+  xn = H.synth.f32_to_bf16_bits(rng.standard_normal((R, E)).astype(np.float32))
+  want = np.zeros((R, E), np.uint16)
+  routing = np.zeros((R, TK), np.int32)
+  O.lib().orc_moe_rows(ctypes.byref(orc.model.c), 1, xn.ctypes.data_as(O._u16p), R, want.ctypes.data_as(O._u16p), routing.ctypes.data_as(O._i32p))
+  x = H.dev_bf16(xn)
+  experts, weights = full.moe_route(1, x)
+  assert np.array_equal(experts.cpu().numpy(), routing)
+  rows = x.repeat_interleave(TK, dim=0).contiguous()                    # one row per (row, k) copy
+  ids = experts.reshape(-1).to(torch.int32)
+  ids_pad = torch.cat([ids, torch.full((3,), -1, dtype=torch.int32, device="cuda")])     # padding rows of the fixed-capacity exchange
+  rows_pad = torch.cat([rows, rows[:3]])
+  parts = [ctx.moe_experts(1, rows_pad, ids_pad) for _, ctx in shards]
+  torch.cuda.synchronize()
+  per = NE // 2
+  y = torch.zeros_like(rows)
+  for rank, part in enumerate(parts):
+    mine = (ids >= rank * per) & (ids < (rank + 1) * per)
+    assert not part[:R * TK][~mine].any() and not part[R * TK:].any()  # rows of other ranks' experts and padding rows: zeros
+    y = torch.where(mine[:, None], part[:R * TK], y)
+  whole = full.moe_experts(1, rows, ids)                                # the same through a context with every expert
+  assert torch.equal(whole, y)
+  for e in range(NE):                                                   # and through the one-expert op of round 2
+    sel = (ids == e).nonzero()[:, 0]
+    if sel.numel():
+      assert torch.equal(full.moe_expert(1, e, rows[sel].contiguous()), y[sel])
+  out = full.moe_combine(y.reshape(R, TK, E).contiguous(), weights)
+  torch.cuda.synchronize()
+  assert np.array_equal(H.bits(out), want)
+  toks, tl = _prompt(cfg.vocab_size, 64, 7), 11
+  with pytest.raises(NotImplementedError):
+    shards[0][0].prefill(params=None, padded_tokens=toks, true_length=tl, slot=0)

@@ -146,3 +146,69 @@ def test_world_size_2_gloo_exchange():
     assert p.exitcode == 0
   assert all(ok and owned for _, ok, owned, _ in res)
   assert sum(n for *_, n in res) == (11 + 5) * 2                      # every (row, k) copy was evaluated exactly once somewhere
+
+
+# ---------------------------------------------------------------- the hot-path form: fixed capacity, one call for all local experts
+def _experts_packed(first, count):
+  """experts_fn of expert_parallel_apply_grouped for experts [first, first + count): padding ids and other ranks' ids -> zero rows."""
+  def fn(rows, ids):
+    out = torch.zeros_like(rows)
+    for i in range(rows.shape[0]):
+      e = int(ids[i])
+      if first <= e < first + count:
+        out[i] = _expert(e, rows[i])
+    return out
+  return fn
+
+
+def test_grouped_single_process_is_the_direct_evaluation():
+  x, sel, _ = _case(0, 13, 2, 8)
+  y = ep.expert_parallel_apply_grouped(x, sel, 8, _experts_packed(0, 8))
+  for r in range(13):
+    for j in range(2):
+      assert torch.equal(y[r, j], _expert(int(sel[r, j]), x[r]))
+  assert torch.equal(y, ep.expert_parallel_apply(x, sel, 8, _expert))
+
+
+def test_grouped_capacity_drops_only_what_does_not_fit():
+  x, sel, _ = _case(3, 9, 2, 8)
+  y = ep.expert_parallel_apply_grouped(x, sel, 8, _experts_packed(0, 8), capacity=5)   # one destination (world 1): copies 0..4 fit
+  flat = y.reshape(18, -1)
+  for p in range(18):
+    r, j = divmod(p, 2)
+    want = _expert(int(sel[r, j]), x[r]) if p < 5 else torch.zeros_like(x[r])
+    assert torch.equal(flat[p], want)
+
+
+def _worker_grouped(rank, world, port, q):
+  dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+  try:
+    n_rows = [11, 5][rank]                      # ragged rows: the capacity is agreed beforehand (the larger rank's rows * k)
+    x, sel, _ = _case(rank, n_rows, 2, 8)
+    seen = []
+
+    def fn(rows, ids):
+      seen.append(int((ids >= 0).sum()))
+      assert all(rank * 4 <= int(e) < rank * 4 + 4 for e in ids[ids >= 0])     # only rows of this rank's experts arrive
+      return _experts_packed(rank * 4, 4)(rows, ids)
+
+    y = ep.expert_parallel_apply_grouped(x, sel, 8, fn, capacity=22)
+    ok = all(torch.equal(y[r, j], _expert(int(sel[r, j]), x[r])) for r in range(n_rows) for j in range(2))
+    q.put((rank, ok, len(seen) == 1, seen[0]))
+  finally:
+    dist.destroy_process_group()
+
+
+def test_grouped_world_size_2_gloo_exchange():
+  ctx = mp.get_context("spawn")
+  q = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker_grouped, args=(r, 2, port, q)) for r in range(2)]
+  for p in procs:
+    p.start()
+  res = [q.get(timeout=120) for _ in procs]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  assert all(ok and once for _, ok, once, _ in res)
+  assert sum(n for *_, n in res) == (11 + 5) * 2                      # every (row, k) copy was evaluated exactly once somewhere

@@ -31,9 +31,15 @@ DeviceTree = synth.DeviceTree                      # weights drawn on the device
 gemma2_spec = mixtral_spec = synth.device_tree_spec
 
 
+OPTS = []          # library options name=value (ixt_set_option) given with --opt: experiments
+
+
 def run(name, cfg, spec, prompt_len, chunk, slots, steps):
   t0 = time.perf_counter()
   eng = maxengine.MaxEngine(cfg)
+  for kv in OPTS:
+    k, v = kv.split("=")
+    importlib.import_module("maxtext-indextts2_amd._lib").check(eng.lib.ixt_set_option(eng._ctx, k.encode(), int(v)))
   params = eng.load_params(params=DeviceTree(spec))
   torch.cuda.synchronize()
   t_load = time.perf_counter() - t0
@@ -71,7 +77,7 @@ def run(name, cfg, spec, prompt_len, chunk, slots, steps):
   nparams = sum(int(np.prod(s)) for _, s, std in spec if std is not None)
   out = {"workload": name, "params": nparams, "weights_gb": nparams * 2 / 1e9, "load_s": round(t_load, 1), "prompt_tokens": prompt_len, "prefill_chunk": chunk,
          "prefill_s": t_prefill, "prefill_tokens_per_s": prompt_len / t_prefill, "decode_slots": slots, "decode_steps": steps,
-         "decode_ms_per_step": t_dec * 1e3, "decode_tokens_per_s": slots / t_dec, "weights_hbm_frac": nparams * 2 / t_dec / 8e12,
+         "options": list(OPTS), "decode_ms_per_step": t_dec * 1e3, "decode_tokens_per_s": slots / t_dec, "weights_hbm_frac": nparams * 2 / t_dec / 8e12,
          "build_id": eng.lib.ixt_build_id().decode() if hasattr(eng.lib, "ixt_build_id") else None}
   print(json.dumps(out), flush=True)
   del eng
@@ -83,7 +89,9 @@ def main():
   ap.add_argument("which", nargs="*", default=["gemma2", "mixtral"])
   ap.add_argument("--layers", type=int, default=0, help="override base_num_decoder_layers (0: the model file's)")
   ap.add_argument("--steps", type=int, default=64)
+  ap.add_argument("--opt", action="append", default=[], help="library option name=value (ixt_set_option)")
   args = ap.parse_args()
+  OPTS.extend(args.opt)
   common = dict(attention="paged", scan_layers=False, pagedattn_tokens_per_page=32, run_name="bench_variants", use_chunked_prefill=True, override_model_config=True)
   if "gemma2" in args.which:
     kw = dict(base_num_decoder_layers=args.layers) if args.layers else {}
@@ -94,7 +102,7 @@ def main():
     kw = dict(base_num_decoder_layers=args.layers) if args.layers else {}
     cfg = pyconfig.initialize(["bench", BASE], model_name="mixtral-8x7b", per_device_batch_size=8.0, max_prefill_predict_length=256, prefill_chunk_size=256,
                               max_target_length=256 + 128, pagedattn_num_pages=8 * 12 + 2, **common, **kw)
-    run("mixtral-8x7b: 256-token prompts, decode on 8 slots (every expert over all rows)", cfg, mixtral_spec(cfg), 256, 256, 8, args.steps)
+    run("mixtral-8x7b: 256-token prompts, decode on 8 slots (routed experts: every copy in the rows of its expert)", cfg, mixtral_spec(cfg), 256, 256, 8, args.steps)
 
 
 if __name__ == "__main__":
