@@ -83,6 +83,12 @@ typedef struct ixt_config {
    * and the other experts' slices are skipped.  ep_size <= 1: every expert.  A sharded context serves ixt_op_moe_route / ixt_op_moe_experts
    * (the two sides of the caller's exchange); the fused engine entry points need every expert and refuse. */
   int32_t ep_rank, ep_size;
+  /* base.yml:93 `quantization: "fp8"` (BASELINE.json configs[3]).  The reference installs fp8 for training only (quantizations.py:289-298) and refuses
+   * it in decode (decode.py:127-128), so the scheme is this build's own, "IXT-FP8-v1" (csrc/ixt_fp8.h): the four projection
+   * kernels of every layer (and every expert) are kept as e4m3 with one f32 scale per output column, activations are quantised to e4m3 per row
+   * and 512-k block on the way in, the products run on v_mfma_f32_16x16x32_fp8_fp8 with f32 accumulation; embedding, norms, attention and the
+   * logits head stay bf16.  Not bit-comparable with the bf16 path: tests/test_gpu_fp8.py states the error. */
+  int32_t fp8_weights;
 } ixt_config;
 
 enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2, IXT_BLOCK_MIXTRAL = 3 };
@@ -231,6 +237,11 @@ int ixt_op_logprob(ixt_ctx* ctx, const float* logits_dev, int rows, const int32_
  * x[i]; a row whose id is negative or belongs to another rank's experts is padding and comes back as zeros.  One launch sequence for all
  * experts (rows are grouped by expert on the device, an expert without rows is never read); no host synchronisation. */
 int ixt_op_moe_experts(ixt_ctx* ctx, int layer, const uint16_t* x, const int32_t* expert_ids, int n, uint16_t* out, void* stream);
+/* The IXT-FP8-v1 dot on caller-supplied operands (a context created with fp8_weights): x bf16 [R][K], w bf16 [K][N] (row-major) -> out f32 [R][N];
+ * w is quantised per column, x per row and 512-k block, exactly as the engine does with a layer's projection kernels (tests). */
+int ixt_op_dot_fp8(ixt_ctx* ctx, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream);
+/* f32 -> e4m3 (OCP, round to nearest even, saturating at 448) -> f32 on the device, n values: the conversion IXT-FP8-v1 quantises with. */
+int ixt_op_fp8_roundtrip(ixt_ctx* ctx, const float* in_dev, float* out_dev, int64_t n, void* stream);
 /* Self-check of the f32 -> bf16 rounding every kernel uses (jax's astype(bfloat16): round to nearest even; the reference's dtype choice,
  * base.yml:86): the hardware conversion against the integer formula over all 2^32 inputs -> number of differing non-NaN inputs plus
  * NaN inputs that do not stay NaN (0 expected). */

@@ -35,7 +35,7 @@ class IxtConfig(ctypes.Structure):
       ("logits_via_embedding", ctypes.c_int32), ("normalize_embedding_logits", ctypes.c_int32),
       ("local_rope_max_timescale", ctypes.c_float), ("query_pre_attn_scalar", ctypes.c_float),
       ("num_experts", ctypes.c_int32), ("num_experts_per_tok", ctypes.c_int32),
-      ("ep_rank", ctypes.c_int32), ("ep_size", ctypes.c_int32),
+      ("ep_rank", ctypes.c_int32), ("ep_size", ctypes.c_int32), ("fp8_weights", ctypes.c_int32),
   ]
 
 BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3, BLOCK_MIXTRAL = 0, 1, 2, 3
@@ -83,6 +83,8 @@ SIGNATURES = {
     "ixt_op_paged_attention": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, vp, ctypes.c_int, vp, vp]),
     "ixt_op_unembed_argmax": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp, vp]),
     "ixt_op_cvt_check": (ctypes.c_int, [vp, c_i64p, vp]),
+    "ixt_op_dot_fp8": (ctypes.c_int, [vp, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
+    "ixt_op_fp8_roundtrip": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_kv_gather": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "ixt_rope_tables": (ctypes.c_int, [vp, c_u16p, c_u16p]),
     "ixt_timing_enable": (ctypes.c_int, [vp, ctypes.c_int]),

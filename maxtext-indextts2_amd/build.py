@@ -10,7 +10,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.path.join(PKG_DIR, "libixt.so")
 SOURCES = ["ixt_api.hip"]
-HEADERS = ["ixt_device.h", "ixt_kernels.h", "ixt_gemma_kernels.h", "ixt_moe_kernels.h", "ixt_gemm.h", "ixt_small.h", "ixt_train_kernels.h", "ixt_train.hip", os.path.join("..", "..", "include", "ixt.h"),
+HEADERS = ["ixt_device.h", "ixt_kernels.h", "ixt_gemma_kernels.h", "ixt_moe_kernels.h", "ixt_gemm.h", "ixt_small.h", "ixt_fp8.h", "ixt_train_kernels.h", "ixt_train.hip", os.path.join("..", "..", "include", "ixt.h"),
            os.path.join("..", "..", "include", "ixt_train.h")]
 
 # -ffp-contract=off: the numerics contract allows fused multiply-adds only where the source

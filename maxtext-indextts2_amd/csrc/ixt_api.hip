@@ -5,6 +5,7 @@
 #include "ixt_gemma_kernels.h"
 #include "ixt_moe_kernels.h"
 #include "ixt_small.h"
+#include "ixt_fp8.h"
 
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -136,6 +137,12 @@ struct ixt_ctx {
   int h_final_rows = 0;
   float* plogits = nullptr;     // [NLmax][V]
   int32_t* pargmax = nullptr;   // [NLmax]
+  // IXT-FP8-v1 (ixt_fp8.h): e4m3 twin + column scales of every projection kernel (made from the bf16 copy on first use), activation workspace
+  struct F8W { uint8_t* w8; float* s; int K, N; };
+  bool fp8 = false, fp8_ready = false;
+  std::map<const bf16_t*, F8W> f8w;
+  uint8_t* x8 = nullptr;        // [rows16][Kmax] e4m3 fragments
+  float* xs8 = nullptr;         // [rows16][chains]
   std::vector<TimingPair> tpairs;
   size_t tused = 0;
   // graphs keyed by the pointer tuple of ixt_generate
@@ -369,6 +376,31 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
     x->xt_cap = (size_t)((R + 15) / 16) * 16 * (kmax > 8192 ? kmax : 8192);
     A(dmalloc(x, &x->xt_op, x->xt_cap));
   }
+  x->fp8 = c.fp8_weights != 0;
+  if (x->fp8) {
+    if (moe && c.ep_size > 1) return fail(set_err(IXT_ERR_UNSUPPORTED, "fp8 weights with expert-sharded contexts are not built"));
+    const int kmax8 = F > x->QN ? (F > E ? F : E) : (x->QN > E ? x->QN : E);
+    A(dmalloc(x, &x->x8, Rp * (size_t)kmax8));
+    A(dmalloc(x, &x->xs8, Rp * (size_t)((kmax8 + IXT_CHAIN - 1) / IXT_CHAIN)));
+    auto twin = [&](const bf16_t* w, int K_, int N_) -> int {
+      ixt_ctx::F8W t{nullptr, nullptr, K_, N_};
+      int r = dmalloc(x, &t.w8, (size_t)K_ * N_);
+      if (r == IXT_OK) r = dmalloc(x, &t.s, (size_t)N_);
+      x->f8w[w] = t;
+      return r;
+    };
+    for (int i = 0; i < L; ++i) {
+      LayerW& w = x->layers[i];
+      A(twin(w.wqkv, E, x->NQKV));
+      A(twin(w.wo, x->QN, E));
+      if (moe) {
+        for (int e = 0; e < x->NEL; ++e) { A(twin(w.ewi[e], E, 2 * F)); A(twin(w.ewout[e], F, E)); }
+      } else {
+        A(twin(w.wi, E, 2 * F));
+        A(twin(w.wout, F, E));
+      }
+    }
+  }
   A(dmalloc(x, &x->row_slot, (size_t)R));
   A(dmalloc(x, &x->row_pos, (size_t)R));
   A(dmalloc(x, &x->row_active, (size_t)R));
@@ -428,6 +460,7 @@ static int tile_param(const void* src, int dtype, bf16_t* dst, int K, int ncols,
 extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr, int dtype, const int64_t* shape, int ndim, void* stream) {
   if (!c || !path || !dev_ptr || !shape) return set_err(IXT_ERR_INVALID, "null argument");
   hipStream_t st = (hipStream_t)stream;
+  c->fp8_ready = false;          // the e4m3 twins are made from the bf16 copies on the next forward pass
   std::string p(path);
   if (p.rfind("params/", 0) == 0) p = p.substr(7);
   int64_t numel = 1;
@@ -786,6 +819,63 @@ static int launch_ring(ixt_ctx* c, int epi, const bf16_t* x, const bf16_t* w, in
 
 struct DotResult { int slices; size_t slice_stride; int ntiles; };
 
+// ---- IXT-FP8-v1 (ixt_fp8.h)
+static int fp8_prepare(ixt_ctx* c, hipStream_t st) {
+  if (!c->fp8 || c->fp8_ready) return IXT_OK;
+  for (auto& kv : c->f8w) {
+    hipLaunchKernelGGL(k_f8_quant_w, dim3(kv.second.N), dim3(256), 0, st, kv.first, kv.second.K, kv.second.N, kv.second.w8, kv.second.s);
+    LAUNCHCHK();
+  }
+  c->fp8_ready = true;
+  return IXT_OK;
+}
+template <int WR, int WC, int RB, int CT, int KS, int NS>
+static int ring_launch8_t(const uint8_t* x8, const uint8_t* w8, int K, int N, int R, const GemmEpi& e, hipStream_t st) {
+  constexpr int TC = WC * CT, TR = WR * RB;
+  const int ncolg = (N / 16 + TC - 1) / TC, zb = (R + 16 * TR - 1) / (16 * TR);
+  constexpr size_t lds = (size_t)NS * (TC + TR) * KS * 1024;
+  static bool attr_done = false;
+  if (!attr_done) {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<WR, WC, RB, CT, KS, NS, GEPI_F32, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((k_gemm_ring<WR, WC, RB, CT, KS, NS, GEPI_F32, 0, true>), dim3(((ncolg + 7) / 8) * 8 * zb), dim3(WR * WC * 64), lds, st,
+                     reinterpret_cast<const u32x4*>(x8), reinterpret_cast<const u32x4*>(w8), K, N, R, ncolg, zb, 0, e);
+  LAUNCHCHK();
+  return IXT_OK;
+}
+// x: bf16 rows in the x layout; t: the kernel's e4m3 twin.  out: f32 [slices][R][N] with the scales applied.
+static int launch_dot8(ixt_ctx* c, const bf16_t* x, const ixt_ctx::F8W& t, int K, int N, int R, float* out, size_t out_floats, hipStream_t st, DotResult* res) {
+  if (K % 64 || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "fp8 dot: K %% 64 or N %% 16");
+  const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN, rowblocks = (R + 15) / 16, ntile = N / 16;
+  hipLaunchKernelGGL(k_f8_quant_x, dim3(chains, rowblocks), dim3(64), 0, st, x, K, R, c->x8, c->xs8);
+  LAUNCHCHK();
+  if (R >= c->ring_min_rows && K % IXT_KALIGN == 0 && (size_t)R * N <= out_floats) {
+    GemmEpi e{};
+    e.out = out; e.xscale = c->xs8; e.wscale = t.s;
+    const int ti = timing_begin(c, st, (double)K * N + (double)R * K + (double)R * N * 4.0);
+    int rc;
+    if ((long)((N + 127) / 128) * ((R + 127) / 128) >= 150 || N % 128 == 0) rc = ring_launch8_t<2, 4, 4, 2, 2, 4>(c->x8, t.w8, K, N, R, e, st);   // 128 x 128 tiles
+    else rc = ring_launch8_t<2, 4, 4, 1, 2, 5>(c->x8, t.w8, K, N, R, e, st);                                                                  // 128 x 64
+    timing_end(c, st, ti);
+    res->slices = 1; res->slice_stride = (size_t)R * N; res->ntiles = ntile;
+    return rc;
+  }
+  if ((size_t)chains * R * N > out_floats) return set_err(IXT_ERR_INVALID, "fp8 dot: output workspace too small");
+  const int nrb = rowblocks >= 3 ? 4 : rowblocks, zblocks = (rowblocks + nrb - 1) / nrb;
+  const int ti = timing_begin(c, st, (double)K * N + (double)R * K + (double)chains * R * N * 4.0);
+  dim3 grid((((ntile + 3) / 4 + 7) / 8) * 8 * zblocks, chains, 1);
+  const u32x4* xp = reinterpret_cast<const u32x4*>(c->x8);
+  const u32x4* wp = reinterpret_cast<const u32x4*>(t.w8);
+  if (nrb == 4) hipLaunchKernelGGL((k_dotb8<4>), grid, dim3(256), (size_t)4 * 8192, st, xp, wp, c->xs8, t.s, K, N, R, out, ntile, zblocks);
+  else if (nrb == 2) hipLaunchKernelGGL((k_dotb8<2>), grid, dim3(256), (size_t)2 * 8192, st, xp, wp, c->xs8, t.s, K, N, R, out, ntile, zblocks);
+  else hipLaunchKernelGGL((k_dotb8<1>), grid, dim3(256), (size_t)8192, st, xp, wp, c->xs8, t.s, K, N, R, out, ntile, zblocks);
+  timing_end(c, st, ti);
+  LAUNCHCHK();
+  res->slices = chains; res->slice_stride = (size_t)R * N; res->ntiles = ntile;
+  return IXT_OK;
+}
+
 // x: bf16 in the dot x layout (xidx); w: bf16 in the tiled weight layout (widx).  out: f32 [slices][R][N]; force_full: one
 // slice (all chains added inside the wave).  Up to 64 rows share each loaded weight fragment (NRB 16-row blocks per block);
 // more rows run as partner blocks on the same XCD.
@@ -793,6 +883,10 @@ static int launch_dot(ixt_ctx* c, const bf16_t* x, const bf16_t* w, int K, int N
                       bool force_full, hipStream_t st, DotResult* res, bool no_ring = false) {
   if (K % IXT_MK || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "dot: K %% 32 or N %% 16");
   if (out == nullptr) return set_err(IXT_ERR_INVALID, "dot: null output");
+  if (c->fp8) {   // a projection kernel with an e4m3 twin: the fp8 matrix cores (everything else -- op-level kernels, the logits head -- stays bf16)
+    auto it = c->f8w.find(w);
+    if (it != c->f8w.end()) return launch_dot8(c, x, it->second, K, N, R, out, out_floats, st, res);
+  }
   const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
   const int ntile = N / 16;
   const int rowblocks = (R + 15) / 16;
@@ -1370,7 +1464,7 @@ static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, cons
 // Few rows (R <= 16, llama2 block): five launches per layer, nothing but K / V pages, q, the attention output and the hidden rows leaves the chip
 // between them (ixt_small.h).  Same results as the other forms bit for bit (tests/test_gpu_small.py compares the two paths of one engine).
 static bool small_path_ok(const ixt_ctx* c, int R) {
-  if (c->small_rows <= 0 || R > c->small_rows || R > 16 || c->moe || c->gemma) return false;
+  if (c->small_rows <= 0 || R > c->small_rows || R > 16 || c->moe || c->gemma || c->fp8) return false;
   return sdot_plan(c, GEPI_QKV, true, c->E, c->NQKV, R).ok && sdot_plan(c, GEPI_RESID, false, c->QN, c->E, R).ok &&
          sdot_plan(c, GEPI_SWIGLU, true, c->E, 2 * c->F, R).ok;
 }
@@ -1441,6 +1535,7 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
 static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, int lrow0, int nl, const int32_t* lrows, int32_t* argmax_out,
                         float* logits_out, bool decode, hipStream_t st) {
   if (!ixt_weights_complete(c)) return set_err(IXT_ERR_NOT_LOADED, "weights incomplete");
+  TRY(fp8_prepare(c, st));
   if (c->gemma) return forward_rows_gemma2(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, st);
   if (c->moe && c->NEL != c->NE) return set_err(IXT_ERR_UNSUPPORTED, "this context holds experts %d..%d of %d: the fused engine needs every expert (expert-parallel contexts serve ixt_op_moe_route / ixt_op_moe_experts)", c->E0, c->E0 + c->NEL - 1, c->NE);
   if (small_path_ok(c, R)) return forward_rows_small(c, R, tokens, len_hint, lrow0, nl, lrows, argmax_out, logits_out, decode, st);
@@ -1449,7 +1544,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
   bf16_t* hcur = c->h_a;
   bf16_t* hnext = c->h_b;
   const bool final_fused = nl == R && lrow0 == 0 && lrows == nullptr;   // decode: every row is unembedded
-  const bool ring = R >= c->ring_min_rows && !c->moe;   // Mixtral: the split-K dots (every expert is a launch sequence of its own)
+  const bool ring = R >= c->ring_min_rows && !c->moe && !c->fp8;   // fp8: the dots write scaled f32 slices, the bf16 path's row kernels take it from there   // Mixtral: the split-K dots (every expert is a launch sequence of its own)
   const int fused_min = c->attn_fused_min_blocks;
   const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
   const bool attn_one_launch = R * c->KV >= fused_min && fused_lds <= 64 * 1024;
@@ -1534,7 +1629,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
       hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
       LAUNCHCHK();
-      if (c->moe_grouped) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
+      if (c->moe_grouped && !c->fp8) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
         DotResult mr;
         TRY(moe_experts_routed(c, w, c->xn, c->moe_idx, R * c->TK, c->TK, st, &mr));
         hipLaunchKernelGGL(k_moe_combine_rows, dim3((E + 255) / 256, R), dim3(256), 0, st, c->part, mr.slices, mr.slice_stride, c->moe_pos, c->moe_w, E, c->TK, c->moe_comb);
@@ -1959,6 +2054,43 @@ __global__ __launch_bounds__(256) void k_cvt_check(unsigned long long* bad) {
     if (nan ? ((hw & 0x7fffu) <= 0x7f80u) : (hw != sw)) ++n;
   }
   if (n) atomicAdd(bad, n);
+}
+// IXT-FP8-v1 dot of caller-supplied operands (tests): x bf16 [R][K] row-major, w bf16 [K][N] row-major -> out f32 [R][N]
+extern "C" int ixt_op_dot_fp8(ixt_ctx* c, const uint16_t* x, const uint16_t* w, float* out, int R, int K, int N, void* stream) {
+  if (!c || !x || !w || !out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  if (!c->fp8) return set_err(IXT_ERR_UNSUPPORTED, "this context was not created with fp8_weights");
+  hipStream_t st = (hipStream_t)stream;
+  if (K % 64 || N % 16) return set_err(IXT_ERR_UNSUPPORTED, "fp8 dot: K %% 64 or N %% 16");
+  if ((size_t)((K + IXT_CHAIN - 1) / IXT_CHAIN) * R * N > c->part_floats) return set_err(IXT_ERR_INVALID, "op: %d x %d outputs exceed the scratch of this ctx", R, N);
+  TRY(transpose_rows(c, x, R, K, st));
+  bf16_t* wt = nullptr;
+  ixt_ctx::F8W t{nullptr, nullptr, K, N};
+  HIPCHK(hipMalloc((void**)&wt, (size_t)K * N * sizeof(bf16_t)));
+  HIPCHK(hipMalloc((void**)&t.w8, (size_t)K * N));
+  HIPCHK(hipMalloc((void**)&t.s, (size_t)N * sizeof(float)));
+  int rc = tile_param(w, IXT_BF16, wt, K, N, 0, st);
+  if (rc == IXT_OK) {
+    hipLaunchKernelGGL(k_f8_quant_w, dim3(N), dim3(256), 0, st, wt, K, N, t.w8, t.s);
+    DotResult dr;
+    // the activation workspace is sized for the model's widest K: the op's K must fit
+    const int kmax8 = std::max(std::max(c->F, c->QN), c->E);
+    if (K > kmax8 || R > c->Rmax) rc = set_err(IXT_ERR_INVALID, "op: %d rows x K %d exceed the fp8 workspace", R, K);
+    else rc = launch_dot8(c, c->xt_op, t, K, N, R, c->part, c->part_floats, st, &dr);
+    if (rc == IXT_OK) {
+      const size_t n = (size_t)R * N;
+      hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c->part, dr.slices, dr.slice_stride, out, n);
+    }
+  }
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(wt); (void)hipFree(t.w8); (void)hipFree(t.s);
+  return rc;
+}
+
+extern "C" int ixt_op_fp8_roundtrip(ixt_ctx* c, const float* in_dev, float* out_dev, int64_t n, void* stream) {
+  if (!c || !in_dev || !out_dev || n <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_f8_roundtrip, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in_dev, out_dev, n);
+  LAUNCHCHK();
+  return IXT_OK;
 }
 extern "C" int ixt_op_cvt_check(ixt_ctx* c, int64_t* mismatches_out, void* stream) {
   if (!c || !mismatches_out) return set_err(IXT_ERR_INVALID, "null argument");

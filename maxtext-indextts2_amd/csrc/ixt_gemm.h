@@ -38,6 +38,7 @@ struct GemmEpi {
   const bf16_t* rope_sin; const bf16_t* rope_cos;
   bf16_t* qbuf; bf16_t* kpages; bf16_t* vpages;
   AttnGeom g;
+  const float* xscale; const float* wscale;             // F8: activation scales [rows][chains], column scales [N] (ixt_fp8.h)
   const int32_t* rb_exp; size_t wstride;                // routed experts: expert of every 16-row block (-1: none), 16-byte units between experts' kernels
 };
 
@@ -48,7 +49,9 @@ __device__ __forceinline__ void ring_wait() {
 
 //   grid = (8 ceil(ncolg / 8) zb, SPLIT ? chains : 1), block 64 WR WC, dynamic LDS = NS (WC CT + WR RB) KS KiB.
 //   Row groups of one column group are block ids b, b + 8, ..: same XCD, the weights meet in its L2.
-template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT>
+//   F8 (ixt_fp8.h): both operands are e4m3 fragments of 64 k (still 1 KiB: the ring moves them exactly as bf16 fragments of 32 k); a fragment
+//   feeds two v_mfma_f32_16x16x32_fp8_fp8; at the end of every 512-k chain the accumulator is scaled by (a_rc s_n) before it joins the total.
+template <int WR, int WC, int RB, int CT, int KS, int NS, int EPI, int SPLIT, bool F8 = false>
 __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                                int ncolg, int zb, int wring, GemmEpi e) {
   constexpr int NW = WR * WC;          // waves
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
     if (ex < 0) return;
     wt += (size_t)ex * e.wstride;
   }
-  const int nsteps = K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;
+  const int nsteps = F8 ? K >> 6 : K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;   // fragments along k
   const int nchunks = nsteps / KS;
   const int wr = wave / WC, wc = wave % WC;
   const int r_in = lane & 15, cq = lane >> 4;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
       src[j] = xt + ((size_t)rb * nsteps + ((f - NWF) % KS)) * 64 + lane;
     }
   }
-  constexpr int CPC = 16 / KS;                                  // chunks per 512-k chain
+  constexpr int CPC = (F8 ? 8 : 16) / KS;                       // chunks per 512-k chain
   const int chb = SPLIT ? (int)blockIdx.y * CPC : 0;
   const int che = SPLIT ? min(nchunks, chb + CPC) : nchunks;
 #define IXT_RISSUE(CH_, SLOT_)                                                                                         \
@@ -147,7 +150,16 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
 #pragma unroll
       for (int i = 0; i < CT; ++i) {
 #pragma unroll
-        for (int b = 0; b < RB; ++b) acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][b], acc[i][b], 0, 0, 0);
+        for (int b = 0; b < RB; ++b) {
+          if constexpr (F8) {
+            typedef long l2 __attribute__((ext_vector_type(2)));
+            const l2 wl = __builtin_bit_cast(l2, wf[ks][i]), xl = __builtin_bit_cast(l2, xf[ks][b]);
+            acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[0], xl[0], acc[i][b], 0, 0, 0);
+            acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(wl[1], xl[1], acc[i][b], 0, 0, 0);
+          } else {
+            acc[i][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][i], xf[ks][b], acc[i][b], 0, 0, 0);
+          }
+        }
         const int gi = ks * CT + i;
         if (refill) {
 #pragma unroll
@@ -160,6 +172,20 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
       }
     }
     if (((ch + 1) % CPC) == 0 || ch + 1 == che) {               // a 512-k chain is complete
+      if constexpr (F8) {                                       // scale the chain by (activation block scale) x (column scale)
+        const int chain = ch / CPC, nchains = (nchunks + CPC - 1) / CPC;
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const int row = min((rowg * TR + wr * RB + b) * 16 + r_in, R - 1);
+          const float a = e.xscale[(size_t)row * nchains + chain];
+#pragma unroll
+          for (int i = 0; i < CT; ++i) {
+            const int tile = min(colg * TC + wc * CT + i, ntile - 1);
+            const float4 sn = *reinterpret_cast<const float4*>(e.wscale + tile * 16 + cq * 4);
+            acc[i][b][0] *= a * sn.x; acc[i][b][1] *= a * sn.y; acc[i][b][2] *= a * sn.z; acc[i][b][3] *= a * sn.w;
+          }
+        }
+      }
 #pragma unroll
       for (int i = 0; i < CT; ++i)
 #pragma unroll

@@ -74,8 +74,8 @@ class MaxEngine(engine_api.Engine):
     self.lib = _lib.load()
     if config.attention not in ("paged", "autoselected"):
       raise NotImplementedError(f"attention={config.attention}: this build implements the paged path only")
-    if config.quantization or config.quantize_kvcache:
-      raise NotImplementedError("quantized weights / KV cache are outside the built path")
+    if config.quantization not in ("", None, "fp8") or config.quantize_kvcache:
+      raise NotImplementedError("quantization: only '' (bf16) and 'fp8' (IXT-FP8-v1: e4m3 projection kernels on the fp8 matrix cores) are built; KV cache quantisation is not")
     if config.decode_sampling_strategy != "greedy":
       raise NotImplementedError("only greedy sampling is built (parity is defined on greedy decode)")
     self.device = torch.device("cuda", torch.cuda.current_device())
@@ -95,6 +95,7 @@ class MaxEngine(engine_api.Engine):
     c.use_hip_graph = 1 if config.ixt_use_hip_graph else 0
     c.max_packed_rows = int(config.ixt_max_packed_rows)
     c.staging_groups = int(config.ixt_staging_groups)
+    c.fp8_weights = 1 if config.quantization == "fp8" else 0
     if config.decoder_block in ("gemma2", "gemma3"):   # layers/gemma2.py:69-236, layers/gemma3.py:35-200
       if tuple(config.mlp_activations) != ("gelu", "linear"):
         raise ValueError(f"decoder_block {config.decoder_block} is built with mlp_activations ['gelu', 'linear']")
@@ -314,8 +315,6 @@ class MaxEngine(engine_api.Engine):
     del params, sampler, rng, decoder_segment_ids
     if existing_prefix:
       raise ValueError("We don't know what to do with existing_prefix")
-    if return_prompt_logp:
-      raise NotImplementedError("return_prompt_logp needs the logits of every prompt row; only the last rows' are computed here")
     n = int(num_prompts)
     if n <= 0 or n > self._staging:
       raise ValueError(f"prefill_concat: num_prompts ({n}) out of range (0, ixt_staging_groups={self._staging}]")
@@ -345,6 +344,13 @@ class MaxEngine(engine_api.Engine):
                                          ctypes.c_void_p(row_pos.data_ptr()), max_len, n, ctypes.c_void_p(ends.data_ptr()),
                                          ctypes.c_void_p(first.data_ptr()),
                                          ctypes.c_void_p(logits.data_ptr()), ctypes.c_void_p(_stream_ptr())))
+    prompt_logp = None
+    if return_prompt_logp:     # maxengine.py:777-778: log_softmax(logits[t])[tokens[t]] at every position of the packed sequence (padding: 0)
+      row_logp = torch.empty((total,), dtype=torch.float32, device=self.device)
+      _lib.check(self.lib.ixt_prefill_prompt_logp(self._ctx, ctypes.c_void_p(row_tok.data_ptr()), total, ctypes.c_void_p(row_logp.data_ptr()),
+                                                  ctypes.c_void_p(_stream_ptr())))
+      prompt_logp = torch.zeros((1, toks.numel()), dtype=torch.float32, device=self.device)
+      prompt_logp[0, idx] = row_logp
     next_pos = torch.tensor(lens, dtype=torch.int32, device=self.device).reshape(n, 1, 1)
     generated = torch.zeros((n, 1, 1), dtype=torch.int32, device=self.device)
     tokens = first.reshape(n, 1, 1)
@@ -354,7 +360,7 @@ class MaxEngine(engine_api.Engine):
       data = torch.cat([tokens[i], torch.ones_like(tokens[i]), generated[i]], dim=1)
       results.append(engine_api.ResultTokens(data=data, tokens_idx=(0, 1), valid_idx=(1, 2), length_idx=(2, 3),
                                              log_prob=logps[i:i + 1] if logps is not None else None, samples_per_slot=1))
-    prefill_results = {"logits": logits, "next_pos": next_pos, "generated_tokens": generated, "tokens": tokens, "prompt_logp": None}
+    prefill_results = {"logits": logits, "next_pos": next_pos, "generated_tokens": generated, "tokens": tokens, "prompt_logp": prompt_logp}
     cache = PagedCacheHandle(self, None, 0, groups=[B + i for i in range(n)], lengths=lens)
     return cache, prefill_results, results
 

@@ -517,9 +517,19 @@ def test_return_log_prob_outputs():
   want = O.logprob_rows(lg, pres["tokens"].reshape(2).cpu().numpy())
   got = np.concatenate([r.log_prob.cpu().numpy().reshape(-1) for r in results])
   assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
-  with pytest.raises(NotImplementedError):      # the packed form is not built
-    eng.prefill_concat(params=params, padded_tokens=t2, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts, true_lengths=ln, num_prompts=2,
-                       return_prompt_logp=True)
+  # return_prompt_logp of the packed form (maxengine.py:777-778): every packed position's log-probability == the one-by-one prefill's == the oracle's
+  _, pres2, _ = eng.prefill_concat(params=params, padded_tokens=t2, decoder_positions=pos, decoder_segment_ids=seg, start_pos=starts, true_lengths=ln,
+                                   num_prompts=2, return_prompt_logp=True)
+  plp = pres2["prompt_logp"].cpu().numpy()
+  assert plp.shape == (1, len(t2))
+  covered = np.zeros(len(t2), bool)
+  for i, (ptoks, tl) in enumerate(prompts):
+    orc2 = H.make_oracle(cfg, w)
+    opre2, _ = orc2.prefill(ptoks, tl, slot=0, want_prompt_logp=True)
+    st0 = int(starts[i])
+    assert np.array_equal(plp[0, st0:st0 + tl].view(np.uint32), opre2["prompt_logp"].view(np.uint32)), i
+    covered[st0:st0 + tl] = True
+  assert not plp[0, ~covered].any()                                                       # padding positions hold 0
   del eng
   torch.cuda.synchronize()
 

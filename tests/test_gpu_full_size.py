@@ -90,3 +90,50 @@ def test_gemma3_4b_seven_layers_chunked_and_graph_invariance():
     del eng
     torch.cuda.empty_cache()
   assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1])
+
+
+def _long_prompt_runs(model, total, plans, steps=3, **kw):
+  """One `total`-token prompt through the engine's chunked prefill under several (chunk size, hipGraph) plans: first token, last-row logits, the last
+  sub-layer's K / V of the whole prompt and `steps` decode steps must agree bit for bit."""
+  import torch
+  outs = []
+  for chunk, use_graph in plans:
+    cfg = H.make_config(model, per_device_batch_size=1.0, max_prefill_predict_length=chunk, max_target_length=total + 64, pagedattn_tokens_per_page=32,
+                        pagedattn_num_pages=(total + 64) // 32 + 2, use_chunked_prefill=True, prefill_chunk_size=chunk, ixt_use_hip_graph=use_graph, **kw)
+    maxengine, eng, params = _engine(cfg)
+    toks = torch.from_numpy(_prompt(cfg.vocab_size, total, 21)).to(eng.device)
+    done, pre, res = 0, None, None
+    while done < total:
+      n = min(chunk, total - done)
+      ep = None if done == 0 else maxengine.ExistingPrefix(cache=pre["cache"], common_prefix_tokens=toks[:done])
+      pre, res = eng.prefill(params=params, padded_tokens=toks[done:done + n], true_length=n, slot=0, existing_prefix=ep)
+      done += n
+    ds = eng.insert(pre, eng.init_decode_state(materialize_logits=True), 0)
+    seq = [int(res.data.cpu().numpy()[0, 0])]
+    for _ in range(steps):
+      ds, r = eng.generate(params, ds)
+      seq.append(int(r.data.cpu().numpy()[0, 0]))
+    k, v = eng.gather_kv(H.sublayers(cfg) - 1, 0, total + steps)
+    outs.append((seq, pre["logits"].cpu().numpy().reshape(-1).view(np.uint32).copy(), ds["logits"][0].cpu().numpy().reshape(-1).view(np.uint32).copy(),
+                 H.bits(k).copy(), H.bits(v).copy()))
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
+  for o in outs[1:]:
+    assert o[0] == outs[0][0]
+    for a, b in zip(o[1:], outs[0][1:]):
+      assert np.array_equal(a, b)
+  lg = outs[0][2].view(np.float32)
+  assert np.isfinite(lg).all() and float(lg.max()) > float(lg.min())
+
+
+def test_gemma2_2b_4096_token_chunked_prefill():
+  """BASELINE.json configs[3]'s workload shape: Gemma-2 2B + the 2048 appended vocabulary rows, every layer, ONE 4096-token prompt (the local
+  sub-layers' window is 4096: the last chunks see the whole prompt).  256-row chunks == 1024-row chunks == one 4096-row pass, hipGraph == eager."""
+  _long_prompt_runs("gemma2-2b", 4096, [(256, True), (1024, False), (4096, True)], vocab_size=256128 + 2048)
+
+
+def test_gemma2_2b_4096_token_chunked_prefill_fp8():
+  """The same workload with `quantization: fp8` (IXT-FP8-v1): the activation scales belong to a row and a 512-k block, so a row's result still does
+  not depend on the launch it runs in -- 256-row chunks == 1024-row chunks, hipGraph == eager, bit for bit."""
+  _long_prompt_runs("gemma2-2b", 4096, [(256, True), (1024, False)], vocab_size=256128 + 2048, quantization="fp8")

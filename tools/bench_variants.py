@@ -77,7 +77,7 @@ def run(name, cfg, spec, prompt_len, chunk, slots, steps):
   nparams = sum(int(np.prod(s)) for _, s, std in spec if std is not None)
   out = {"workload": name, "params": nparams, "weights_gb": nparams * 2 / 1e9, "load_s": round(t_load, 1), "prompt_tokens": prompt_len, "prefill_chunk": chunk,
          "prefill_s": t_prefill, "prefill_tokens_per_s": prompt_len / t_prefill, "decode_slots": slots, "decode_steps": steps,
-         "options": list(OPTS), "decode_ms_per_step": t_dec * 1e3, "decode_tokens_per_s": slots / t_dec, "weights_hbm_frac": nparams * 2 / t_dec / 8e12,
+         "options": list(OPTS), "quantization": str(cfg.quantization or "bf16"), "decode_ms_per_step": t_dec * 1e3, "decode_tokens_per_s": slots / t_dec, "weights_hbm_frac": nparams * 2 / t_dec / 8e12,
          "build_id": eng.lib.ixt_build_id().decode() if hasattr(eng.lib, "ixt_build_id") else None}
   print(json.dumps(out), flush=True)
   del eng
@@ -90,9 +90,12 @@ def main():
   ap.add_argument("--layers", type=int, default=0, help="override base_num_decoder_layers (0: the model file's)")
   ap.add_argument("--steps", type=int, default=64)
   ap.add_argument("--opt", action="append", default=[], help="library option name=value (ixt_set_option)")
+  ap.add_argument("--fp8", action="store_true", help="quantization: fp8 (IXT-FP8-v1: e4m3 projection kernels on the fp8 matrix cores)")
   args = ap.parse_args()
   OPTS.extend(args.opt)
   common = dict(attention="paged", scan_layers=False, pagedattn_tokens_per_page=32, run_name="bench_variants", use_chunked_prefill=True, override_model_config=True)
+  if args.fp8:
+    common["quantization"] = "fp8"
   if "gemma2" in args.which:
     kw = dict(base_num_decoder_layers=args.layers) if args.layers else {}
     cfg = pyconfig.initialize(["bench", BASE], model_name="gemma2-2b", vocab_size=256128 + 2048, per_device_batch_size=8.0, max_prefill_predict_length=256,
