@@ -347,6 +347,9 @@ def run_rank(args):
         torch.cuda.empty_cache()
         return None
 
+    if world > 1:                            # the rows below describe ONE GPU: on a multi-rank run the other ranks would only wait for them
+      args.no_batch_rows = args.no_big_rows = True
+      budget.skipped.append({"row": "batch_rows, long_prefill, big_batch_rows", "reason": f"single-GPU rows are not run at n_gpus = {world}"})
     if not args.no_batch_rows:
       rows = [optional(f"batch_rows[{b}]", 12.0 + 3.2 * args.decode_steps / 1024, lambda b=b: batch_row(args, b, weights, prompts_dev, nums)) for b in (1, 8)]
       out["detail"]["batch_rows"] = [r for r in rows if r is not None]

@@ -43,6 +43,7 @@ struct LayerAct {   // saved for the backward pass
 struct ixt_trainer {
   ixt_train_config cfg;
   int E, H, D, F, V, L, B, S, T, QN, Tc;
+  int KVH, G, KN;           // grouped-query attention: kv heads, query heads per kv head, KVH * D
   std::vector<ParamInfo> params;
   long total = 0;
   // caller-owned flat buffers
@@ -59,6 +60,7 @@ struct ixt_trainer {
   float *scores = nullptr, *dh = nullptr, *dxn = nullptr, *logits = nullptr, *row_loss = nullptr, *scal = nullptr, *part = nullptr;
   bf16_t *tmp_bf = nullptr, *dS = nullptr, *d_ao = nullptr, *dq = nullptr, *dk = nullptr, *dv = nullptr, *dact = nullptr, *da = nullptr, *db = nullptr, *dlog = nullptr,
          *dy_bf = nullptr;
+  float *dkf = nullptr, *dvf = nullptr;   // grouped-query attention: dK / dV summed over a group's query heads in f32 before they round to bf16
   std::vector<void*> allocs;
 };
 
@@ -79,7 +81,7 @@ static void add_param(ixt_trainer* t, const std::string& name, long numel, long*
 
 extern "C" int ixt_train_create(const ixt_train_config* c, ixt_trainer** out) {
   if (!c || !out) return t_set_err(IXT_ERR_INVALID, "null argument");
-  if (c->num_query_heads != c->num_kv_heads) return t_set_err(IXT_ERR_UNSUPPORTED, "train step: grouped-query attention is not built (query heads == kv heads)");
+  if (c->num_kv_heads <= 0 || c->num_query_heads % c->num_kv_heads) return t_set_err(IXT_ERR_INVALID, "train step: num_query_heads %% num_kv_heads != 0");
   if (c->head_dim % 8 || c->emb_dim % 8 || c->mlp_dim % 8 || c->vocab_size % 8 || c->seq_len % 8)
     return t_set_err(IXT_ERR_UNSUPPORTED, "train step: every dimension must be a multiple of 8");
   if (c->batch <= 0 || c->seq_len <= 0 || c->num_decoder_layers <= 0) return t_set_err(IXT_ERR_INVALID, "bad sizes");
@@ -87,17 +89,18 @@ extern "C" int ixt_train_create(const ixt_train_config* c, ixt_trainer** out) {
   t->cfg = *c;
   t->E = c->emb_dim; t->H = c->num_query_heads; t->D = c->head_dim; t->F = c->mlp_dim; t->V = c->vocab_size; t->L = c->num_decoder_layers;
   t->B = c->batch; t->S = c->seq_len; t->T = t->B * t->S; t->QN = t->H * t->D;
+  t->KVH = c->num_kv_heads; t->G = t->H / t->KVH; t->KN = t->KVH * t->D;
   t->Tc = c->logits_chunk > 0 ? c->logits_chunk : 2048;
   if (t->Tc > t->T) t->Tc = t->T;
-  const long E = t->E, F = t->F, V = t->V, QN = t->QN;
+  const long E = t->E, F = t->F, V = t->V, QN = t->QN, KN = t->KN;
   add_param(t, "params/token_embedder/embedding", V * E, &t->o_emb);
   t->lo.resize(t->L);
   for (int i = 0; i < t->L; ++i) {
     const std::string p = "params/decoder/layers_" + std::to_string(i) + "/";
     add_param(t, p + "pre_self_attention_layer_norm/scale", E, &t->lo[i].ln1);
     add_param(t, p + "self_attention/query/kernel", E * QN, &t->lo[i].wq);
-    add_param(t, p + "self_attention/key/kernel", E * QN, &t->lo[i].wk);
-    add_param(t, p + "self_attention/value/kernel", E * QN, &t->lo[i].wv);
+    add_param(t, p + "self_attention/key/kernel", E * KN, &t->lo[i].wk);
+    add_param(t, p + "self_attention/value/kernel", E * KN, &t->lo[i].wv);
     add_param(t, p + "self_attention/out/kernel", QN * E, &t->lo[i].wo);
     add_param(t, p + "mlp/mlp_layer_norm/scale", E, &t->lo[i].ln2);
     add_param(t, p + "mlp/wi_0/kernel", E * F, &t->lo[i].wi0);
@@ -115,7 +118,7 @@ extern "C" int ixt_train_create(const ixt_train_config* c, ixt_trainer** out) {
   t->act.resize(t->L);
   for (int i = 0; i < t->L; ++i) {
     LayerAct& a = t->act[i];
-    A(tmalloc(t, &a.h_in, T * E)); A(tmalloc(t, &a.xn1, T * E)); A(tmalloc(t, &a.q, T * QN)); A(tmalloc(t, &a.k, T * QN)); A(tmalloc(t, &a.v, T * QN));
+    A(tmalloc(t, &a.h_in, T * E)); A(tmalloc(t, &a.xn1, T * E)); A(tmalloc(t, &a.q, T * QN)); A(tmalloc(t, &a.k, T * KN)); A(tmalloc(t, &a.v, T * KN));
     A(tmalloc(t, &a.P, BH * S * S)); A(tmalloc(t, &a.ao, T * QN)); A(tmalloc(t, &a.h_mid, T * E)); A(tmalloc(t, &a.xn2, T * E));
     A(tmalloc(t, &a.a, T * F)); A(tmalloc(t, &a.b, T * F)); A(tmalloc(t, &a.act, T * F)); A(tmalloc(t, &a.r1, T)); A(tmalloc(t, &a.r2, T));
   }
@@ -124,8 +127,9 @@ extern "C" int ixt_train_create(const ixt_train_config* c, ixt_trainer** out) {
   A(tmalloc(t, &t->logits, (size_t)t->Tc * V)); A(tmalloc(t, &t->dlog, (size_t)t->Tc * V)); A(tmalloc(t, &t->row_loss, T)); A(tmalloc(t, &t->scal, (size_t)16));
   A(tmalloc(t, &t->part, (size_t)4096));
   const size_t big = T * (size_t)(F > QN ? (F > E ? F : E) : (QN > E ? QN : E));
-  A(tmalloc(t, &t->tmp_bf, big)); A(tmalloc(t, &t->dS, BH * S * S)); A(tmalloc(t, &t->d_ao, T * QN)); A(tmalloc(t, &t->dq, T * QN)); A(tmalloc(t, &t->dk, T * QN));
-  A(tmalloc(t, &t->dv, T * QN)); A(tmalloc(t, &t->dact, T * F)); A(tmalloc(t, &t->da, T * F)); A(tmalloc(t, &t->db, T * F)); A(tmalloc(t, &t->dy_bf, T * E));
+  A(tmalloc(t, &t->tmp_bf, big)); A(tmalloc(t, &t->dS, BH * S * S)); A(tmalloc(t, &t->d_ao, T * QN)); A(tmalloc(t, &t->dq, T * QN)); A(tmalloc(t, &t->dk, T * KN));
+  A(tmalloc(t, &t->dv, T * KN));
+  if (t->G > 1) { A(tmalloc(t, &t->dkf, T * KN)); A(tmalloc(t, &t->dvf, T * KN)); } A(tmalloc(t, &t->dact, T * F)); A(tmalloc(t, &t->da, T * F)); A(tmalloc(t, &t->db, T * F)); A(tmalloc(t, &t->dy_bf, T * E));
 #undef A
   // RoPE tables: the same host recipe as the decode path (embeddings.py:270-307)
   {
@@ -205,7 +209,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     return t_set_err(IXT_ERR_INVALID, "null argument");
   if (!t->p) return t_set_err(IXT_ERR_INVALID, "bind the parameter buffers first");
   hipStream_t st = (hipStream_t)stream;
-  const int E = t->E, H = t->H, D = t->D, F = t->F, V = t->V, S = t->S, T = t->T, QN = t->QN, B = t->B;
+  const int E = t->E, H = t->H, D = t->D, F = t->F, V = t->V, S = t->S, T = t->T, QN = t->QN, B = t->B, KVH = t->KVH, G = t->G, KN = t->KN;
   const long HD = (long)H * D;
   const bf16_t* pb = t->pb;
   const float eps = t->cfg.normalization_layer_epsilon;
@@ -219,14 +223,19 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     const ixt_trainer::LOff& o = t->lo[l];
     hipLaunchKernelGGL(k_t_rmsnorm_fwd, dim3(T), dim3(256), 0, st, a.h_in, pb + o.ln1, a.xn1, a.r1, E, eps);
     TTRY(gemm(st, a.xn1, E, 1, pb + o.wq, QN, 1, a.q, QN, T, QN, E, 1, 0));
-    TTRY(gemm(st, a.xn1, E, 1, pb + o.wk, QN, 1, a.k, QN, T, QN, E, 1, 0));
-    TTRY(gemm(st, a.xn1, E, 1, pb + o.wv, QN, 1, a.v, QN, T, QN, E, 1, 0));
+    TTRY(gemm(st, a.xn1, E, 1, pb + o.wk, KN, 1, a.k, KN, T, KN, E, 1, 0));
+    TTRY(gemm(st, a.xn1, E, 1, pb + o.wv, KN, 1, a.v, KN, T, KN, E, 1, 0));
     hipLaunchKernelGGL((k_t_rope<false>), dim3(T, H), dim3(D / 2), 0, st, a.q, positions, t->rope_sin, t->rope_cos, H, D);
-    hipLaunchKernelGGL((k_t_rope<false>), dim3(T, H), dim3(D / 2), 0, st, a.k, positions, t->rope_sin, t->rope_cos, H, D);
-    // scores[b,h] = Q K^T (sm_scale 1: the query kernel carries 1/sqrt(d), attentions.py:1900-1904)
-    TTRY(gemm(st, a.q, HD, 1, a.k, 1, HD, t->scores, S, S, S, D, 0, 0, B, H, (long)S * HD, D, (long)S * HD, D, (long)H * S * S, (long)S * S));
+    hipLaunchKernelGGL((k_t_rope<false>), dim3(T, KVH), dim3(D / 2), 0, st, a.k, positions, t->rope_sin, t->rope_cos, KVH, D);
+    // scores[b,h] = Q_h K_(h / G)^T (sm_scale 1: the query kernel carries 1/sqrt(d), attentions.py:1900-1904).  Grouped-query attention
+    // (attentions.py:1206-1271: query heads reshaped to [kv heads, G]): query head kvh G + g of every kv head in launch g, batches (b, kvh).
+    for (int g = 0; g < G; ++g)
+      TTRY(gemm(st, a.q + (long)g * D, HD, 1, a.k, 1, KN, t->scores + (long)g * S * S, S, S, S, D, 0, 0, B, KVH, (long)S * HD, (long)G * D, (long)S * KN, D,
+                (long)H * S * S, (long)G * S * S));
     hipLaunchKernelGGL(k_t_softmax_fwd, dim3(S, B * H), dim3(256), 0, st, t->scores, segmentation, a.P, S, H);
-    TTRY(gemm(st, a.P, S, 1, a.v, HD, 1, a.ao, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
+    for (int g = 0; g < G; ++g)
+      TTRY(gemm(st, a.P + (long)g * S * S, S, 1, a.v, KN, 1, a.ao + (long)g * D, HD, S, D, S, 1, 0, B, KVH, (long)H * S * S, (long)G * S * S, (long)S * KN, D,
+                (long)S * HD, (long)G * D));
     TTRY(gemm(st, a.ao, QN, 1, pb + o.wo, E, 1, t->tmp_bf, E, T, E, QN, 1, 0));
     hipLaunchKernelGGL(k_t_add_bf16, EW((long)T * E), a.h_in, t->tmp_bf, a.h_mid, (long)T * E);
     hipLaunchKernelGGL(k_t_rmsnorm_fwd, dim3(T), dim3(256), 0, st, a.h_mid, pb + o.ln2, a.xn2, a.r2, E, eps);
@@ -274,20 +283,39 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     hipLaunchKernelGGL(k_t_f32_to_bf16, EW((long)T * E), t->dh, t->dy_bf, (long)T * E);
     TTRY(gemm(st, t->dy_bf, E, 1, pb + o.wo, 1, E, t->d_ao, QN, T, QN, E, 1, 0));                        // d ao = dy . Wo^T
     TTRY(gemm(st, a.ao, 1, QN, t->dy_bf, E, 1, t->g + o.wo, E, QN, E, T, 0, 0));                          // d Wo = ao^T . dy
-    // dP = d_ao V^T (f32) ; dV = P^T d_ao ; dS = P o (dP - rowsum(dP o P)) ; dQ = dS K ; dK = dS^T Q
-    TTRY(gemm(st, t->d_ao, HD, 1, a.v, 1, HD, t->scores, S, S, S, D, 0, 0, B, H, (long)S * HD, D, (long)S * HD, D, (long)H * S * S, (long)S * S));
-    TTRY(gemm(st, a.P, 1, S, t->d_ao, HD, 1, t->dv, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
+    // dP = d_ao V^T (f32) ; dV = P^T d_ao ; dS = P o (dP - rowsum(dP o P)) ; dQ = dS K ; dK = dS^T Q.  With G query heads per kv head, dV and dK
+    // are the sums over the group: accumulated in f32 over the G launches, rounded to bf16 once.
+    for (int g = 0; g < G; ++g)
+      TTRY(gemm(st, t->d_ao + (long)g * D, HD, 1, a.v, 1, KN, t->scores + (long)g * S * S, S, S, S, D, 0, 0, B, KVH, (long)S * HD, (long)G * D, (long)S * KN, D,
+                (long)H * S * S, (long)G * S * S));
+    if (G == 1) {
+      TTRY(gemm(st, a.P, 1, S, t->d_ao, HD, 1, t->dv, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
+    } else {
+      for (int g = 0; g < G; ++g)
+        TTRY(gemm(st, a.P + (long)g * S * S, 1, S, t->d_ao + (long)g * D, HD, 1, t->dvf, KN, S, D, S, 0, g > 0, B, KVH, (long)H * S * S, (long)G * S * S,
+                  (long)S * HD, (long)G * D, (long)S * KN, D));
+      hipLaunchKernelGGL(k_t_f32_to_bf16, EW((long)T * KN), t->dvf, t->dv, (long)T * KN);
+    }
     hipLaunchKernelGGL(k_t_softmax_bwd, dim3(S, B * H), dim3(256), 0, st, t->scores, a.P, t->dS, S);
-    TTRY(gemm(st, t->dS, S, 1, a.k, HD, 1, t->dq, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
-    TTRY(gemm(st, t->dS, 1, S, a.q, HD, 1, t->dk, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
+    for (int g = 0; g < G; ++g)
+      TTRY(gemm(st, t->dS + (long)g * S * S, S, 1, a.k, KN, 1, t->dq + (long)g * D, HD, S, D, S, 1, 0, B, KVH, (long)H * S * S, (long)G * S * S, (long)S * KN, D,
+                (long)S * HD, (long)G * D));
+    if (G == 1) {
+      TTRY(gemm(st, t->dS, 1, S, a.q, HD, 1, t->dk, HD, S, D, S, 1, 0, B, H, (long)H * S * S, (long)S * S, (long)S * HD, D, (long)S * HD, D));
+    } else {
+      for (int g = 0; g < G; ++g)
+        TTRY(gemm(st, t->dS + (long)g * S * S, 1, S, a.q + (long)g * D, HD, 1, t->dkf, KN, S, D, S, 0, g > 0, B, KVH, (long)H * S * S, (long)G * S * S,
+                  (long)S * HD, (long)G * D, (long)S * KN, D));
+      hipLaunchKernelGGL(k_t_f32_to_bf16, EW((long)T * KN), t->dkf, t->dk, (long)T * KN);
+    }
     hipLaunchKernelGGL((k_t_rope<true>), dim3(T, H), dim3(D / 2), 0, st, t->dq, positions, t->rope_sin, t->rope_cos, H, D);
-    hipLaunchKernelGGL((k_t_rope<true>), dim3(T, H), dim3(D / 2), 0, st, t->dk, positions, t->rope_sin, t->rope_cos, H, D);
+    hipLaunchKernelGGL((k_t_rope<true>), dim3(T, KVH), dim3(D / 2), 0, st, t->dk, positions, t->rope_sin, t->rope_cos, KVH, D);
     TTRY(gemm(st, t->dq, QN, 1, pb + o.wq, 1, QN, t->dxn, E, T, E, QN, 0, 0));                           // d xn1 = dq Wq^T + dk Wk^T + dv Wv^T
-    TTRY(gemm(st, t->dk, QN, 1, pb + o.wk, 1, QN, t->dxn, E, T, E, QN, 0, 1));
-    TTRY(gemm(st, t->dv, QN, 1, pb + o.wv, 1, QN, t->dxn, E, T, E, QN, 0, 1));
+    TTRY(gemm(st, t->dk, KN, 1, pb + o.wk, 1, KN, t->dxn, E, T, E, KN, 0, 1));
+    TTRY(gemm(st, t->dv, KN, 1, pb + o.wv, 1, KN, t->dxn, E, T, E, KN, 0, 1));
     TTRY(gemm(st, a.xn1, 1, E, t->dq, QN, 1, t->g + o.wq, QN, E, QN, T, 0, 0));
-    TTRY(gemm(st, a.xn1, 1, E, t->dk, QN, 1, t->g + o.wk, QN, E, QN, T, 0, 0));
-    TTRY(gemm(st, a.xn1, 1, E, t->dv, QN, 1, t->g + o.wv, QN, E, QN, T, 0, 0));
+    TTRY(gemm(st, a.xn1, 1, E, t->dk, KN, 1, t->g + o.wk, KN, E, KN, T, 0, 0));
+    TTRY(gemm(st, a.xn1, 1, E, t->dv, KN, 1, t->g + o.wv, KN, E, KN, T, 0, 0));
     hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3(T), dim3(256), 0, st, t->dxn, a.h_in, pb + o.ln1, a.r1, t->dh, t->g + o.ln1, E);
     TLAUNCH();
   }

@@ -79,6 +79,8 @@ class TrainOracle:
   def loss(self, batch):
     c = self.cfg
     E, H, D, F, V, L = c.emb_dim, c.num_query_heads, c.head_dim, c.mlp_dim, c.vocab_size, c.num_decoder_layers
+    KVH = int(c.num_kv_heads)
+    G = H // KVH                                     # grouped-query attention (attentions.py:1206-1271): G query heads share a kv head
     tok = torch.as_tensor(np.asarray(batch["inputs"]), dtype=torch.long)
     pos = torch.as_tensor(np.asarray(batch["inputs_position"]), dtype=torch.long)
     seg = torch.as_tensor(np.asarray(batch["inputs_segmentation"]), dtype=torch.long)
@@ -91,8 +93,10 @@ class TrainOracle:
       pre = f"params/decoder/layers_{i}/"
       xn = self._norm(h, self.p[pre + "pre_self_attention_layer_norm/scale"])
       q = self._rope(rb(xn @ w(pre + "self_attention/query/kernel", (E, H * D))).reshape(B, S, H, D), pos)
-      k = self._rope(rb(xn @ w(pre + "self_attention/key/kernel", (E, H * D))).reshape(B, S, H, D), pos)
-      v = rb(xn @ w(pre + "self_attention/value/kernel", (E, H * D))).reshape(B, S, H, D)
+      k = self._rope(rb(xn @ w(pre + "self_attention/key/kernel", (E, KVH * D))).reshape(B, S, KVH, D), pos)
+      v = rb(xn @ w(pre + "self_attention/value/kernel", (E, KVH * D))).reshape(B, S, KVH, D)
+      if G > 1:                                      # query head h attends to kv head h // G
+        k, v = k.repeat_interleave(G, dim=2), v.repeat_interleave(G, dim=2)
       sc = torch.einsum("bihd,bjhd->bhij", q, k).masked_fill(~mask[:, None], float("-inf"))
       p = rb(torch.softmax(sc, dim=-1))
       ao = rb(torch.einsum("bhij,bjhd->bihd", p, v)).reshape(B, S, H * D)

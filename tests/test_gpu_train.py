@@ -42,12 +42,18 @@ def packed_batch(cfg, seed):
   return b
 
 
-@pytest.mark.parametrize("shape", ["tiny", "wide"])
+@pytest.mark.parametrize("shape", ["tiny", "wide", "gqa", "gqa4"])
 def test_train_steps_match_oracle(shape):
   import torch
   tr = importlib.import_module("maxtext-indextts2_amd.train")
   if shape == "tiny":
     cfg = train_config()
+  elif shape == "gqa":      # grouped-query attention, two query heads per kv head (every Gemma / Mixtral configuration has groups)
+    cfg = train_config(base_emb_dim=128, base_num_query_heads=4, base_num_kv_heads=2, head_dim=32, base_mlp_dim=256, vocab_size=512, max_target_length=40,
+                       per_device_batch_size=2.0, learning_rate=3e-3)
+  elif shape == "gqa4":     # four query heads per kv head (Mixtral-8x7B's 32 / 8), one kv head only
+    cfg = train_config(base_emb_dim=128, base_num_query_heads=4, base_num_kv_heads=1, head_dim=32, base_mlp_dim=256, vocab_size=512, max_target_length=24,
+                       per_device_batch_size=3.0, learning_rate=3e-3)
   else:
     cfg = train_config(base_emb_dim=256, base_num_query_heads=4, base_num_kv_heads=4, head_dim=64, base_mlp_dim=512, vocab_size=1024, max_target_length=136,
                        per_device_batch_size=3.0, learning_rate=3e-3)
@@ -111,10 +117,39 @@ def test_free_running_trajectory_stays_close():
   torch.cuda.synchronize()
 
 
+def test_train_step_at_the_c3_widths():
+  """BASELINE.json configs[2]'s model at its real widths -- emb 2048, 16 heads of 128, mlp 7168, the 264 192-row audio-expanded vocabulary, 2048-token
+  rows -- with 2 of its 16 layers and one row per step (the CPU oracle is an f32 torch autograd pass: the logits alone are 2 GB): loss within 1e-4
+  relative with synchronised state, raw gradient norm within 3e-3, every gradient tensor within 2 %."""
+  import torch
+  tr = importlib.import_module("maxtext-indextts2_amd.train")
+  cfg = H.make_config(model_name="indextts2-1b", base_num_decoder_layers=2, per_device_batch_size=1.0, max_target_length=2048, steps=10, learning_rate=1e-4,
+                      warmup_steps_fraction=0.2)
+  torch.set_num_threads(16)
+  params = f32_params(cfg, 6)
+  trainer = tr.Trainer(cfg)
+  trainer.load_params(params)
+  orc = TO.TrainOracle(cfg, params)
+  b = packed_batch(cfg, 31)
+  m = trainer.train_step(b)
+  g_hip = {k: v.clone() for k, v in trainer.param_views(trainer.grads).items()}
+  o = orc.train_step(b)
+  assert m["learning/total_weights"] == o["learning/total_weights"]
+  assert abs(m["learning/loss"] - o["learning/loss"]) <= 1e-4 * abs(o["learning/loss"]), (m["learning/loss"], o["learning/loss"])
+  assert abs(m["learning/raw_grad_norm"] - o["learning/raw_grad_norm"]) <= 3e-3 * o["learning/raw_grad_norm"], (m, o["learning/raw_grad_norm"])
+  denom = o["learning/total_weights"] + 1e-8
+  for k, g in g_hip.items():
+    ref = o["grads"][k]
+    err = float((g.cpu() / denom - ref).norm()) / (float(ref.norm()) + 1e-12)
+    assert err < 2e-2, (k, err)
+  del trainer
+  torch.cuda.synchronize()
+
+
 def test_trainer_rejects_what_it_does_not_build():
   tr = importlib.import_module("maxtext-indextts2_amd.train")
-  with pytest.raises(NotImplementedError):
-    tr.Trainer(H.make_config(per_device_batch_size=1.0, max_target_length=16))     # ixt-tiny has 4 query / 2 kv heads: grouped-query attention
+  with pytest.raises(ValueError):
+    tr.Trainer(train_config(base_num_query_heads=3, base_num_kv_heads=2, base_emb_dim=96))     # query heads must be a multiple of the kv heads
   cfg = train_config()
   t = tr.Trainer(cfg)
   with pytest.raises(ValueError):
