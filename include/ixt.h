@@ -89,6 +89,10 @@ typedef struct ixt_config {
    * and 512-k block on the way in, the products run on v_mfma_f32_16x16x32_fp8_fp8 with f32 accumulation; embedding, norms, attention and the
    * logits head stay bf16.  Not bit-comparable with the bf16 path: tests/test_gpu_fp8.py states the error. */
   int32_t fp8_weights;
+  /* base.yml:599-600 `rope_type: "llama3.1"` (layers/embeddings.py:354-488 LLaMARotaryEmbedding): the rotation pairs are the NEIGHBOURING features
+   * (2 i, 2 i + 1), sin / cos are f32 and the result rounds to bf16 once; rope_use_scale applies the llama-3.1 frequency scaling
+   * (factor 8, low / high frequency factors 1 / 4, original context 8192; :417-443).  0: the default RotaryEmbedding (:216-351).  llama2 block only. */
+  int32_t rope_llama31, rope_use_scale;
 } ixt_config;
 
 enum { IXT_BLOCK_LLAMA2 = 0, IXT_BLOCK_GEMMA2 = 1, IXT_BLOCK_GEMMA3 = 2, IXT_BLOCK_MIXTRAL = 3 };
@@ -250,6 +254,8 @@ int ixt_op_cvt_check(ixt_ctx* ctx, int64_t* mismatches_out, void* stream);
 int ixt_kv_gather(ixt_ctx* ctx, int layer, int slot, int length, uint16_t* k_out, uint16_t* v_out, void* stream);
 /* RoPE tables (bf16 bit patterns) to HOST arrays [max_target_length][head_dim/2]. */
 int ixt_rope_tables(ixt_ctx* ctx, uint16_t* sin_out, uint16_t* cos_out);
+/* rope_llama31 contexts: the f32 tables of LLaMARotaryEmbedding to HOST arrays [max_target_length][head_dim/2]. */
+int ixt_rope_tables_f32(ixt_ctx* ctx, float* sin_out, float* cos_out);
 
 /* Live measurement hook for bench.py: average duration in microseconds of the named kernel family over the
  * launches made by this ctx since the last ixt_timing_reset, measured with HIP events on the launch stream.

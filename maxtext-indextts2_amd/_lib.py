@@ -36,6 +36,7 @@ class IxtConfig(ctypes.Structure):
       ("local_rope_max_timescale", ctypes.c_float), ("query_pre_attn_scalar", ctypes.c_float),
       ("num_experts", ctypes.c_int32), ("num_experts_per_tok", ctypes.c_int32),
       ("ep_rank", ctypes.c_int32), ("ep_size", ctypes.c_int32), ("fp8_weights", ctypes.c_int32),
+      ("rope_llama31", ctypes.c_int32), ("rope_use_scale", ctypes.c_int32),
   ]
 
 BLOCK_LLAMA2, BLOCK_GEMMA2, BLOCK_GEMMA3, BLOCK_MIXTRAL = 0, 1, 2, 3
@@ -87,6 +88,7 @@ SIGNATURES = {
     "ixt_op_fp8_roundtrip": (ctypes.c_int, [vp, vp, vp, ctypes.c_int64, vp]),
     "ixt_kv_gather": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp, vp, vp]),
     "ixt_rope_tables": (ctypes.c_int, [vp, c_u16p, c_u16p]),
+    "ixt_rope_tables_f32": (ctypes.c_int, [vp, vp, vp]),
     "ixt_timing_enable": (ctypes.c_int, [vp, ctypes.c_int]),
     "ixt_timing_reset": (ctypes.c_int, [vp]),
     "ixt_timing_get": (ctypes.c_int, [vp, ctypes.c_char_p, c_f64p, c_i64p, c_f64p]),

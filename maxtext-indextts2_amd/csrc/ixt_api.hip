@@ -67,6 +67,8 @@ struct ixt_ctx {
   bf16_t *rope_sin = nullptr, *rope_cos = nullptr;
   bf16_t *rope_sin_local = nullptr, *rope_cos_local = nullptr;   // Gemma-3 local layers (local_rope_max_timescale); nullptr: the tables above
   std::vector<uint16_t> rope_sin_h, rope_cos_h;
+  std::vector<float> rope_sin32_h, rope_cos32_h;   // rope_type "llama3.1": f32 tables; rope_sin / rope_cos then point at their device copies
+  bool rope32 = false;
   std::vector<bf16_t*> kpages_l, vpages_l;   // one allocation per layer: [page][kv_head][...]
   bf16_t **kptrs_d = nullptr, **vptrs_d = nullptr;   // the same pointers in HBM (k_pages_copy)
   size_t layer_page_elems = 0;
@@ -194,6 +196,40 @@ static void host_rope_tables(const ixt_config& cfg, float max_timescale, std::ve
     }
 }
 
+// LLaMARotaryEmbedding (embeddings.py:396-443): timescale_i = min (max / min)^(2 i / D) for the pair (2 i, 2 i + 1); with use_scale the
+// frequency 1 / timescale goes through the llama-3.1 rule: wavelengths below 8192 / 4 keep it, above 8192 divide it by 8, between the two the
+// smooth blend.  angle = position / timescale in f32; sin / cos evaluated in double and rounded to f32.
+static void host_rope_tables_llama31(const ixt_config& cfg, std::vector<float>& sn, std::vector<float>& cs) {
+  const int half = cfg.head_dim / 2, T = cfg.max_target_length;
+  sn.resize((size_t)T * half);
+  cs.resize((size_t)T * half);
+  std::vector<float> ts(half);
+  for (int i = 0; i < half; ++i) {
+    const float frac = (float)(2 * i) / (float)cfg.head_dim;
+    float t = (float)((double)cfg.rope_min_timescale * pow((double)cfg.rope_max_timescale / (double)cfg.rope_min_timescale, (double)frac));
+    if (cfg.rope_use_scale) {
+      const float scale_factor = 8.0f, low = 1.0f, high = 4.0f, old_len = 8192.0f;
+      float freq = 1.0f / t;
+      const float wavelen = 2.0f * 3.14159265358979323846f / freq;
+      if (wavelen < old_len / high) {
+      } else if (wavelen > old_len / low) {
+        freq = freq / scale_factor;
+      } else {
+        const float smooth = (old_len / wavelen - low) / (high - low);
+        freq = (1.0f - smooth) * freq / scale_factor + smooth * freq;
+      }
+      t = 1.0f / freq;
+    }
+    ts[i] = t;
+  }
+  for (int p = 0; p < T; ++p)
+    for (int i = 0; i < half; ++i) {
+      const float ang = (float)p / ts[i];
+      sn[(size_t)p * half + i] = (float)sin((double)ang);
+      cs[(size_t)p * half + i] = (float)cos((double)ang);
+    }
+}
+
 static int sdot_set_attributes();
 
 extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
@@ -303,11 +339,25 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   }
   // RoPE tables
   host_rope_tables(c, c.rope_max_timescale, x->rope_sin_h, x->rope_cos_h);
+  x->rope32 = c.rope_llama31 != 0;
+  if (x->rope32) {
+    if (gemma || moe) return fail(set_err(IXT_ERR_UNSUPPORTED, "rope_type llama3.1 is built for the llama2 block"));
+    host_rope_tables_llama31(c, x->rope_sin32_h, x->rope_cos32_h);
+    float *s32 = nullptr, *c32 = nullptr;
+    A(dmalloc(x, &s32, x->rope_sin32_h.size()));
+    A(dmalloc(x, &c32, x->rope_cos32_h.size()));
+    if (hipMemcpy(s32, x->rope_sin32_h.data(), x->rope_sin32_h.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(c32, x->rope_cos32_h.data(), x->rope_cos32_h.size() * 4, hipMemcpyHostToDevice) != hipSuccess)
+      return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
+    x->rope_sin = reinterpret_cast<bf16_t*>(s32);     // the kernels read them as f32 when AttnGeom.rope32 is set (ixt_rope_pair)
+    x->rope_cos = reinterpret_cast<bf16_t*>(c32);
+  } else {
   A(dmalloc(x, &x->rope_sin, x->rope_sin_h.size()));
   A(dmalloc(x, &x->rope_cos, x->rope_cos_h.size()));
   if (hipMemcpy(x->rope_sin, x->rope_sin_h.data(), x->rope_sin_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemcpy(x->rope_cos, x->rope_cos_h.data(), x->rope_cos_h.size() * 2, hipMemcpyHostToDevice) != hipSuccess)
     return fail(set_err(IXT_ERR_HIP, "rope table upload failed"));
+  }
   if (gemma3 && c.local_rope_max_timescale > 0.0f) {   // attentions.py:2085-2088
     std::vector<uint16_t> sl, cl;
     host_rope_tables(c, c.local_rope_max_timescale, sl, cl);
@@ -415,7 +465,7 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
 #undef A
   AttnGeom& g = x->geom;
   g.nq = x->Q; g.nkv = x->KV; g.hd = x->D; g.P = x->P; g.num_pages = c.pagedattn_num_pages; g.mpg = x->mpg;
-  g.Tmax = x->Tmax; g.nsb_max = x->nsb_max;
+  g.Tmax = x->Tmax; g.nsb_max = x->nsb_max; g.rope32 = x->rope32 ? 1 : 0;
   hipLaunchKernelGGL(k_pages_reset, dim3(1), dim3(64), 0, 0, x->ps);
   if (hipDeviceSynchronize() != hipSuccess) return fail(set_err(IXT_ERR_HIP, "page state init failed"));
   if (sdot_set_attributes() != IXT_OK) return fail(IXT_ERR_HIP);
@@ -547,8 +597,8 @@ extern "C" int ixt_load_weight(ixt_ctx* c, const char* path, const void* dev_ptr
     if (rest.rfind("mlp/", 0) == 0) return set_err(IXT_ERR_INVALID, "unknown parameter path %s (decoder_block mixtral has MoeBlock_0, no mlp)", path);
   }
   if (rest == "pre_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln1, 1, E, E, st)); m |= 1u << W_LN1; }
-  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st, 1, c->D)); m |= 1u << W_Q; }
-  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st, 1, c->D)); m |= 1u << W_K; }
+  else if (rest == "self_attention/query/kernel") { TRY(expect((int64_t)E * c->QN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->QN, 0, st, c->rope32 ? 3 : 1, c->D)); m |= 1u << W_Q; }
+  else if (rest == "self_attention/key/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN, st, c->rope32 ? 3 : 1, c->D)); m |= 1u << W_K; }
   else if (rest == "self_attention/value/kernel") { TRY(expect((int64_t)E * c->KN)); TRY(tile_param(dev_ptr, dtype, w.wqkv, E, c->KN, c->QN + c->KN, st)); m |= 1u << W_V; }
   else if (rest == "self_attention/out/kernel") { TRY(expect((int64_t)c->QN * E)); TRY(tile_param(dev_ptr, dtype, w.wo, c->QN, E, 0, st)); m |= 1u << W_O; }
   else if (rest == "mlp/mlp_layer_norm/scale" || rest == "post_self_attention_layer_norm/scale") { TRY(expect(E)); TRY(copy_param(dev_ptr, dtype, w.ln2, 1, E, E, st)); m |= 1u << W_LN2; }
@@ -1563,7 +1613,8 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       } else if (attn_one_launch) {
         const DotResult none{0, 0, 0};
         const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
-        TRY(launch_attention_fused(c, l, R, none, false, st));   // q from qbuf, every key / value (the new ones too) from the pages
+        if (decode && attn_small_fits(c, R)) TRY(launch_attn_small(c, l, R, st));   // (small_attn_max_blocks raised: the 8-wave form with everything in flight)
+        else TRY(launch_attention_fused(c, l, R, none, false, st));   // q from qbuf, every key / value (the new ones too) from the pages
         timing_end(c, st, ta);
       } else {
         TRY(launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st));
@@ -1927,7 +1978,7 @@ extern "C" int ixt_op_rmsnorm(ixt_ctx* c, const uint16_t* x, const uint16_t* sca
 
 extern "C" int ixt_op_rope(ixt_ctx* c, uint16_t* x, const int32_t* pos, int R, int nheads, void* stream) {
   if (!c || !x || !pos || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
-  hipLaunchKernelGGL(k_rope, dim3(R, nheads), dim3(c->D / 2), 0, (hipStream_t)stream, x, pos, c->rope_sin, c->rope_cos, nheads, c->D);
+  hipLaunchKernelGGL(k_rope, dim3(R, nheads), dim3(c->D / 2), 0, (hipStream_t)stream, x, pos, c->rope_sin, c->rope_cos, nheads, c->D, c->rope32 ? 1 : 0);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -2000,6 +2051,14 @@ extern "C" int ixt_rope_tables(ixt_ctx* c, uint16_t* sin_out, uint16_t* cos_out)
   if (!c || !sin_out || !cos_out) return set_err(IXT_ERR_INVALID, "null argument");
   memcpy(sin_out, c->rope_sin_h.data(), c->rope_sin_h.size() * 2);
   memcpy(cos_out, c->rope_cos_h.data(), c->rope_cos_h.size() * 2);
+  return IXT_OK;
+}
+
+extern "C" int ixt_rope_tables_f32(ixt_ctx* c, float* sin_out, float* cos_out) {
+  if (!c || !sin_out || !cos_out) return set_err(IXT_ERR_INVALID, "null argument");
+  if (!c->rope32) return set_err(IXT_ERR_UNSUPPORTED, "this context was not created with rope_llama31");
+  memcpy(sin_out, c->rope_sin32_h.data(), c->rope_sin32_h.size() * 4);
+  memcpy(cos_out, c->rope_cos32_h.data(), c->rope_cos32_h.size() * 4);
   return IXT_OK;
 }
 

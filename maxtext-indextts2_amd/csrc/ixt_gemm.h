@@ -310,6 +310,15 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
         if (!is_v) {
           // pair-interleaved tile: lanes cq 0,1 hold x1 = features 8 th + 4 (cq & 1) + j, lanes cq 2,3 the partners x2 = half + the same
           const int fi = 8 * th + 4 * (cq & 1);
+          if (g.rope32) {   // rope_type "llama3.1": f32 tables, one rounding (ixt_rope_pair)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const float other = __shfl_xor(v[j], 32, 64);
+              float o1, o2;
+              ixt_rope_pair(1, e.rope_sin, e.rope_cos, (size_t)pos * half + fi + j, cq < 2 ? v[j] : other, cq < 2 ? other : v[j], o1, o2);
+              v[j] = cq < 2 ? o1 : o2;
+            }
+          } else {
           float sn[4], cs[4];
           {
             const uint2 sv = *reinterpret_cast<const uint2*>(e.rope_sin + (size_t)pos * half + fi);
@@ -323,11 +332,20 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
             // first half: bf16(bf16(x1 c) - bf16(x2 s)); second half: bf16(bf16(x2 c) + bf16(x1 s))
             v[j] = cq < 2 ? rbf(rbf(v[j] * cs[j]) - rbf(other * sn[j])) : rbf(rbf(v[j] * cs[j]) + rbf(other * sn[j]));
           }
+          }
         }
         if (tile >= ntile || !row_ok) continue;
         uint2 ov;
         ov.x = pack2(f2bf(v[0]), f2bf(v[1])); ov.y = pack2(f2bf(v[2]), f2bf(v[3]));
-        if (hh < g.nq) {
+        if (g.rope32 && !is_v) {   // llama3.1: the lane's four de-interleaved features are every second feature of the model's order (ixt_qk_feat)
+          const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int fn_ = ixt_qk_feat(1, feat + j, half);
+            if (hh < g.nq) e.qbuf[((size_t)row * g.nq + hh) * g.hd + fn_] = f2bf(v[j]);
+            else if (wr_kv) e.kpages[kpage_off(g, page, hh - g.nq, fn_ >> 3, tok) + (fn_ & 7)] = f2bf(v[j]);
+          }
+        } else if (hh < g.nq) {
           const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
           *reinterpret_cast<uint2*>(e.qbuf + ((size_t)row * g.nq + hh) * g.hd + feat) = ov;
         } else if (!is_v) {

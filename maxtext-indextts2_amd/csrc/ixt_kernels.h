@@ -514,6 +514,7 @@ __global__ void k_tile_w(const T* __restrict__ src, bf16_t* __restrict__ dst, in
   if constexpr (sizeof(T) == 2) v = src[i]; else v = f2bf(src[i]);
   int col;
   if (mode == 1) col = n_off + (n / hd) * hd + qk_col(n % hd, hd >> 1);
+  else if (mode == 3) { const int f = n % hd; col = n_off + (n / hd) * hd + qk_col((f & 1) ? (hd >> 1) + (f >> 1) : (f >> 1), hd >> 1); }   // llama3.1: de-interleave, then as mode 1
   else if (mode == 2) col = ((n >> 4) * 2 + n_off) * 16 + (n & 15);
   else col = n_off + n;
   dst[ring ? r8idx(k, col, K) : widx(k, col, K)] = v;
@@ -718,7 +719,30 @@ struct AttnGeom {
   int nq, nkv, hd, P, num_pages, mpg;   // mpg = max_pages_per_group
   int Tmax;                             // scores row pitch
   int nsb_max;                          // super-blocks per row (pvpart pitch)
+  int rope32;                           // 1: rope_type "llama3.1" (embeddings.py:354-488): the tables are f32, one rounding at the end (ixt_rope_pair)
 };
+
+// Where feature f of the kernels' de-interleaved Q / K order goes in the q buffer and the K pages: its place in the MODEL's order (llama3.1:
+// position i of the first half is feature 2 i, of the second half feature 2 i + 1), so that every score is the same fma chain over d as the
+// oracle's; the default form keeps f.
+__device__ __forceinline__ int ixt_qk_feat(int rope32, int f, int half) { return rope32 ? (f < half ? 2 * f : 2 * (f - half) + 1) : f; }
+
+// One RoPE pair (x1, x2) at table index idx.  Default RotaryEmbedding (embeddings.py:277-315): bf16 tables, every product and the final sum round
+// to bf16.  LLaMARotaryEmbedding (embeddings.py:354-488, rope_type "llama3.1"): `inputs * cos + inputs_shifted * sin * sign` with f32 sin / cos,
+// evaluated in f32 and cast to bf16 once.  The llama3.1 pairs are the NEIGHBOURING features (2i, 2i + 1); the engine stores the Q / K kernels'
+// columns de-interleaved (even features first: k_tile_w mode 3), so that the pair sits at (i, half + i) here as for the default form; the
+// rotated values go back to their places in the model's feature order (ixt_qk_feat).
+__device__ __forceinline__ void ixt_rope_pair(int rope32, const bf16_t* sn, const bf16_t* cs, size_t idx, float x1, float x2, float& o1, float& o2) {
+  if (rope32) {
+    const float s = reinterpret_cast<const float*>(sn)[idx], c = reinterpret_cast<const float*>(cs)[idx];
+    o1 = rbf(x1 * c - x2 * s);
+    o2 = rbf(x2 * c + x1 * s);
+  } else {
+    const float s = bf2f(sn[idx]), c = bf2f(cs[idx]);
+    o1 = rbf(rbf(x1 * c) - rbf(x2 * s));
+    o2 = rbf(rbf(x2 * c) + rbf(x1 * s));
+  }
+}
 
 __device__ __forceinline__ size_t kpage_off(const AttnGeom& g, int page, int kvh, int dchunk, int tok) {
   return ((((size_t)page * g.nkv + kvh) * (g.hd / 8) + dchunk) * g.P + tok) * 8;
@@ -786,10 +810,8 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
       v2 = rbf(sum_slices<16>(pq + (is_v ? half + i : qk_col(half + i, half)), a.slice_stride, a.slices));
     }
     if (!is_v) {
-      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
-      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
-      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
-      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      float o1, o2;
+      ixt_rope_pair(g.rope32, a.rope_sin, a.rope_cos, (size_t)pos * half + i, v1, v2, o1, o2);
       v1 = o1;
       v2 = o2;
       if (qs != 0.0f) {
@@ -797,10 +819,11 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
         v2 = rbf(v2 * qs);
       }
     }
+    const int f1 = is_v ? i : ixt_qk_feat(g.rope32, i, half), f2 = is_v ? half + i : ixt_qk_feat(g.rope32, half + i, half);
     if (hh < g.nq) {
       bf16_t* q = a.qbuf + ((size_t)r * g.nq + hh) * g.hd;
-      q[i] = f2bf(v1);
-      q[half + i] = f2bf(v2);
+      q[f1] = f2bf(v1);
+      q[f2] = f2bf(v2);
       continue;
     }
     if (!a.row_active[r]) continue;
@@ -808,8 +831,8 @@ __global__ __launch_bounds__(64) void k_qkv_finalize(QkvArgs a) {
     const int tok = pos % g.P;
     if (!is_v) {
       const int kvh = hh - g.nq;
-      a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
-      a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+      a.kpages[kpage_off(g, page, kvh, f1 / 8, tok) + (f1 & 7)] = f2bf(v1);
+      a.kpages[kpage_off(g, page, kvh, f2 / 8, tok) + (f2 & 7)] = f2bf(v2);
     } else {
       const int kvh = hh - g.nq - g.nkv;
       bf16_t* v = a.vpages + vpage_off(g, page, kvh, tok);
@@ -942,20 +965,19 @@ __global__ __launch_bounds__(256) void k_attn_front_decode(FrontArgs a) {
     float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
     float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
     if (which <= GQ) {
-      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
-      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
-      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
-      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      float o1, o2;
+      ixt_rope_pair(g.rope32, a.rope_sin, a.rope_cos, (size_t)pos * half + i, v1, v2, o1, o2);
       v1 = o1; v2 = o2;
     }
+    const int f1 = ixt_qk_feat(g.rope32, i, half), f2 = ixt_qk_feat(g.rope32, half + i, half);   // (query / key rows only)
     if (which < GQ) {
-      qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+      qs[which * HD + f1] = v1; qs[which * HD + f2] = v2;
     } else if (which == GQ) {
-      kn[i] = v1; kn[half + i] = v2;
+      kn[f1] = v1; kn[f2] = v2;
       if (sp == 0) {
         const int page = prow[pos / g.P], tok = pos % g.P;
-        a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
-        a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+        a.kpages[kpage_off(g, page, kvh, f1 / 8, tok) + (f1 & 7)] = f2bf(v1);
+        a.kpages[kpage_off(g, page, kvh, f2 / 8, tok) + (f2 & 7)] = f2bf(v2);
       }
     } else {
       const int page = prow[pos / g.P], tok = pos % g.P;
@@ -1208,19 +1230,18 @@ __global__ __launch_bounds__(256) void k_attn_decode(DecAttnArgs a) {
     float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
     float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
     if (which <= GQ) {
-      const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
-      const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
-      const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
-      const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+      float o1, o2;
+      ixt_rope_pair(g.rope32, a.rope_sin, a.rope_cos, (size_t)pos * half + i, v1, v2, o1, o2);
       v1 = o1; v2 = o2;
     }
     const int page = prow[pos / g.P], tok = pos % g.P;
+    const int f1 = ixt_qk_feat(g.rope32, i, half), f2 = ixt_qk_feat(g.rope32, half + i, half);   // (query / key rows only)
     if (which < GQ) {
-      qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+      qs[which * HD + f1] = v1; qs[which * HD + f2] = v2;
     } else if (which == GQ) {
-      kn[i] = v1; kn[half + i] = v2;
-      a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
-      a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+      kn[f1] = v1; kn[f2] = v2;
+      a.kpages[kpage_off(g, page, kvh, f1 / 8, tok) + (f1 & 7)] = f2bf(v1);
+      a.kpages[kpage_off(g, page, kvh, f2 / 8, tok) + (f2 & 7)] = f2bf(v2);
     } else {
       vn[i] = v1; vn[half + i] = v2;
       bf16_t* vd = a.vpages + vpage_off(g, page, kvh, tok);
@@ -1461,18 +1482,17 @@ __global__ __launch_bounds__(256) void k_attn_decode_w(DecAttnArgs a, int npairs
       float v1 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(i, half) : i), a.slice_stride, a.slices));
       float v2 = rbf(sum_slices<16>(pq + (rope_ ? qk_col(half + i, half) : half + i), a.slice_stride, a.slices));
       if (which <= GQ) {
-        const float sn = bf2f(a.rope_sin[(size_t)pos * half + i]);
-        const float cs = bf2f(a.rope_cos[(size_t)pos * half + i]);
-        const float o1 = rbf(rbf(v1 * cs) - rbf(v2 * sn));
-        const float o2 = rbf(rbf(v2 * cs) + rbf(v1 * sn));
+        float o1, o2;
+        ixt_rope_pair(g.rope32, a.rope_sin, a.rope_cos, (size_t)pos * half + i, v1, v2, o1, o2);
         v1 = o1; v2 = o2;
       }
+      const int f1 = ixt_qk_feat(g.rope32, i, half), f2 = ixt_qk_feat(g.rope32, half + i, half);   // (query / key rows only)
       if (which < GQ) {
-        qs[which * HD + i] = v1; qs[which * HD + half + i] = v2;
+        qs[which * HD + f1] = v1; qs[which * HD + f2] = v2;
       } else if (which == GQ) {
-        kn[i] = v1; kn[half + i] = v2;
-        a.kpages[kpage_off(g, page, kvh, i / 8, tok) + (i & 7)] = f2bf(v1);
-        a.kpages[kpage_off(g, page, kvh, (half + i) / 8, tok) + ((half + i) & 7)] = f2bf(v2);
+        kn[f1] = v1; kn[f2] = v2;
+        a.kpages[kpage_off(g, page, kvh, f1 / 8, tok) + (f1 & 7)] = f2bf(v1);
+        a.kpages[kpage_off(g, page, kvh, f2 / 8, tok) + (f2 & 7)] = f2bf(v2);
       } else {
         vn[i] = v1; vn[half + i] = v2;
         bf16_t* vd = a.vpages + vpage_off(g, page, kvh, tok);
@@ -1986,14 +2006,16 @@ __global__ __launch_bounds__(256) void k_logprob(const float* __restrict__ logit
 // =====================================================================================================
 // RoPE on dense rows (op-level).  grid = (R, nheads), block = hd/2.
 // =====================================================================================================
-__global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, const bf16_t* rope_cos, int nheads, int hd) {
+// rope32 (rope_type "llama3.1"): the pair of table index i is the NEIGHBOURING features (2 i, 2 i + 1) of the caller's row (embeddings.py:446-458).
+__global__ void k_rope(bf16_t* x, const int32_t* pos, const bf16_t* rope_sin, const bf16_t* rope_cos, int nheads, int hd, int rope32) {
   const int r = blockIdx.x, h = blockIdx.y, i = threadIdx.x, half = hd / 2;
   if (i >= half) return;
   bf16_t* p = x + ((size_t)r * nheads + h) * hd;
-  const float x1 = bf2f(p[i]), x2 = bf2f(p[half + i]);
-  const float sn = bf2f(rope_sin[(size_t)pos[r] * half + i]), cs = bf2f(rope_cos[(size_t)pos[r] * half + i]);
-  p[i] = f2bf(rbf(x1 * cs) - rbf(x2 * sn));
-  p[half + i] = f2bf(rbf(x2 * cs) + rbf(x1 * sn));
+  const int i1 = rope32 ? 2 * i : i, i2 = rope32 ? 2 * i + 1 : half + i;
+  float o1, o2;
+  ixt_rope_pair(rope32, rope_sin, rope_cos, (size_t)pos[r] * half + i, bf2f(p[i1]), bf2f(p[i2]), o1, o2);
+  p[i1] = f2bf(o1);
+  p[i2] = f2bf(o2);
 }
 
 // =====================================================================================================

@@ -197,23 +197,41 @@ __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
     const int hh = col0 / g.hd, th = tile % tph;
     if (!is_v) {
       const int fi = 8 * th + 4 * (cq & 1);
-      float sn[4], cs_[4];
-      {
-        const uint2 sv = *reinterpret_cast<const uint2*>(a.e.rope_sin + (size_t)pos * half + fi);
-        const uint2 cv = *reinterpret_cast<const uint2*>(a.e.rope_cos + (size_t)pos * half + fi);
-        sn[0] = bflo(sv.x); sn[1] = bfhi(sv.x); sn[2] = bflo(sv.y); sn[3] = bfhi(sv.y);
-        cs_[0] = bflo(cv.x); cs_[1] = bfhi(cv.x); cs_[2] = bflo(cv.y); cs_[3] = bfhi(cv.y);
-      }
+      if (g.rope32) {   // rope_type "llama3.1": f32 tables, one rounding (ixt_rope_pair)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float other = __shfl_xor(v[j], 32, 64);
-        v[j] = cq < 2 ? rbf(rbf(v[j] * cs_[j]) - rbf(other * sn[j])) : rbf(rbf(v[j] * cs_[j]) + rbf(other * sn[j]));
+        for (int j = 0; j < 4; ++j) {
+          const float other = __shfl_xor(v[j], 32, 64);
+          float o1, o2;
+          ixt_rope_pair(1, a.e.rope_sin, a.e.rope_cos, (size_t)pos * half + fi + j, cq < 2 ? v[j] : other, cq < 2 ? other : v[j], o1, o2);
+          v[j] = cq < 2 ? o1 : o2;
+        }
+      } else {
+        float sn[4], cs_[4];
+        {
+          const uint2 sv = *reinterpret_cast<const uint2*>(a.e.rope_sin + (size_t)pos * half + fi);
+          const uint2 cv = *reinterpret_cast<const uint2*>(a.e.rope_cos + (size_t)pos * half + fi);
+          sn[0] = bflo(sv.x); sn[1] = bfhi(sv.x); sn[2] = bflo(sv.y); sn[3] = bfhi(sv.y);
+          cs_[0] = bflo(cv.x); cs_[1] = bfhi(cv.x); cs_[2] = bflo(cv.y); cs_[3] = bfhi(cv.y);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float other = __shfl_xor(v[j], 32, 64);
+          v[j] = cq < 2 ? rbf(rbf(v[j] * cs_[j]) - rbf(other * sn[j])) : rbf(rbf(v[j] * cs_[j]) + rbf(other * sn[j]));
+        }
       }
     }
     if (!row_ok) return;
     uint2 ov;
     ov.x = pack2(f2bf(v[0]), f2bf(v[1])); ov.y = pack2(f2bf(v[2]), f2bf(v[3]));
-    if (hh < g.nq) {
+    if (g.rope32 && !is_v) {   // llama3.1: the lane's four de-interleaved features are every second feature of the model's order (ixt_qk_feat)
+      const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int fn_ = ixt_qk_feat(1, feat + j, half);
+        if (hh < g.nq) a.e.qbuf[((size_t)row * g.nq + hh) * g.hd + fn_] = f2bf(v[j]);
+        else if (wr_kv) a.e.kpages[kpage_off(g, page, hh - g.nq, fn_ >> 3, tok) + (fn_ & 7)] = f2bf(v[j]);
+      }
+    } else if (hh < g.nq) {
       const int feat = (cq >= 2 ? half : 0) + 8 * th + 4 * (cq & 1);
       *reinterpret_cast<uint2*>(a.e.qbuf + ((size_t)row * g.nq + hh) * g.hd + feat) = ov;
     } else if (!is_v) {

@@ -80,8 +80,21 @@ def rotary_embedding_as_linen(*, min_timescale: int, max_timescale: int, embeddi
 
 
 class LLaMARotaryEmbedding(RotaryEmbedding):
-  """embeddings.py:354-488 (llama3.1 frequency scaling): optional in SURVEY.md section 8 (a8) and not built -- the context's tables are the
-  default RoPE's."""
+  """embeddings.py:354-488: the rotation pairs are the neighbouring features (2 i, 2 i + 1), sin / cos are f32, the result is cast to bf16 once;
+  `use_scale` = the llama-3.1 frequency scaling (:417-443).  The tables live in the context, which must have been built with
+  rope_type "llama3.1" and the same use_scale (ixt_config.rope_llama31 / rope_use_scale)."""
 
-  def __init__(self, *args, **kwargs):
-    raise NotImplementedError("rope_type=llama3.1 (LLaMARotaryEmbedding) is outside the built path; rope_type=default is")
+  def __init__(self, min_timescale: int, max_timescale: int, embedding_dims: int = 0, cast_as_fprop_dtype: bool = True, fprop_dtype: Any = None,
+               use_scale: bool = True, rngs: Any = None, config: Any = None, name: Optional[str] = None):
+    super().__init__(min_timescale, max_timescale, embedding_dims, cast_as_fprop_dtype, fprop_dtype, rngs=rngs, config=config, name=name)
+    c = self.ctx.config
+    if not str(c.rope_type).lower().startswith("llama3.1") or bool(c.rope_use_scale) != bool(use_scale):
+      raise ValueError("LLaMARotaryEmbedding: the context was not built with rope_type llama3.1 and this use_scale")
+    self.use_scale = use_scale
+
+
+def llama_rotary_embedding_as_linen(*, min_timescale: int, max_timescale: int, embedding_dims: int = 0, use_scale: bool = True, name: Optional[str] = None,
+                                    config: Any = None, **kwargs):
+  """embeddings.py:318-351."""
+  del kwargs
+  return LLaMARotaryEmbedding(min_timescale, max_timescale, embedding_dims, use_scale=use_scale, config=config, name=name)

@@ -96,6 +96,11 @@ class MaxEngine(engine_api.Engine):
     c.max_packed_rows = int(config.ixt_max_packed_rows)
     c.staging_groups = int(config.ixt_staging_groups)
     c.fp8_weights = 1 if config.quantization == "fp8" else 0
+    rope_type = str(config.rope_type).lower()      # attentions.py:2052-2071
+    if rope_type.startswith("llama3.1") or str(config.model_name).startswith("llama3.1"):
+      c.rope_llama31, c.rope_use_scale = 1, 1 if config.rope_use_scale else 0
+    elif rope_type != "default":
+      raise NotImplementedError(f"rope_type {config.rope_type}: 'default' and 'llama3.1' are built")
     if config.decoder_block in ("gemma2", "gemma3"):   # layers/gemma2.py:69-236, layers/gemma3.py:35-200
       if tuple(config.mlp_activations) != ("gelu", "linear"):
         raise ValueError(f"decoder_block {config.decoder_block} is built with mlp_activations ['gelu', 'linear']")

@@ -81,6 +81,8 @@ class Trainer:
   def __init__(self, config: Any, batch: Optional[int] = None, seq_len: Optional[int] = None, logits_chunk: int = 0, exchange: str = "auto"):
     if not torch.cuda.is_available():
       raise _lib.IxtError("Trainer needs a ROCm GPU: there is no CPU path")
+    if str(config.rope_type).lower() != "default":
+      raise NotImplementedError(f"train step: rope_type {config.rope_type} is not built (the default RotaryEmbedding is)")
     self.config, self.lib = config, _lib.load()
     _signatures(self.lib)
     self.device = torch.device("cuda", torch.cuda.current_device())

@@ -82,6 +82,9 @@ typedef struct orc_model {
    * sum_k weight_k * MLP_{expert_k}(x).  ln2 is post_self_attention_layer_norm; wi0 / wi1 / wout hold all experts of a layer. */
   int32_t n_exp, top_k;               /* num_experts, num_experts_per_tok (<= 8) */
   const uint16_t* const* gate;        /* [L] -> [emb][n_exp]  MoeBlock_0/gate/kernel; wi0/wi1: [L] -> [n_exp][emb][mlp]; wout: [L] -> [n_exp][mlp][emb] */
+  /* rope_type "llama3.1" (layers/embeddings.py:354-488 LLaMARotaryEmbedding): f32 tables [max_pos][hd/2]; NULL: the default RotaryEmbedding */
+  const float* rope_sin32;
+  const float* rope_cos32;
 } orc_model;
 
 /* ---------------------------------------------------------------- scalars */
@@ -245,6 +248,23 @@ void orc_rope(uint16_t* v, int nh, int hd, const uint16_t* sn, const uint16_t* c
       float d = rbf(x2 * c), e = rbf(x1 * s);
       p[i] = f2bf(a - b);
       p[half + i] = f2bf(d + e);
+    }
+  }
+}
+
+/* LLaMARotaryEmbedding.__call__ (embeddings.py:446-488): outputs = inputs * cos + inputs_shifted * sin * sign, in f32 (bf16 inputs times f32
+ * tables promote), cast to bf16 once.  The features of a head stay in their natural order: pair i = (2 i, 2 i + 1), inputs_shifted swaps
+ * the two, sign = (-1, +1).  v: bf16 [nh][hd] in place; sin / cos f32 [hd/2] of this position. */
+void orc_rope_llama31(uint16_t* v, int nh, int hd, const float* sn, const float* cs) {
+  for (int h = 0; h < nh; ++h) {
+    uint16_t* p = v + (size_t)h * hd;
+    for (int i = 0; i < hd / 2; ++i) {
+      const float xe = bf2f(p[2 * i]), xo = bf2f(p[2 * i + 1]);
+      const float s = sn[i], c = cs[i];
+      const float a = xe * c, b = (xo * s) * -1.0f;     /* even feature: its shifted partner is the odd one, sign -1 */
+      const float d = xo * c, e = (xe * s) * 1.0f;      /* odd feature: partner the even one, sign +1 */
+      p[2 * i] = f2bf(a + b);
+      p[2 * i + 1] = f2bf(d + e);
     }
   }
 }
@@ -737,8 +757,13 @@ void orc_forward(const orc_model* m, int R, const int32_t* tokens, const int32_t
         for (int hh = 0; hh < nq; ++hh) orc_rmsnorm(q + (size_t)r * QN + (size_t)hh * hd, m->qn[L], q + (size_t)r * QN + (size_t)hh * hd, hd, m->eps);
       if (m->kn)
         for (int hh = 0; hh < nkv; ++hh) orc_rmsnorm(k + (size_t)r * KN + (size_t)hh * hd, m->kn[L], k + (size_t)r * KN + (size_t)hh * hd, hd, m->eps);
-      orc_rope(q + (size_t)r * QN, nq, hd, sn, cs);
-      orc_rope(k + (size_t)r * KN, nkv, hd, sn, cs);
+      if (m->rope_sin32) {
+        orc_rope_llama31(q + (size_t)r * QN, nq, hd, m->rope_sin32 + (size_t)pos[r] * (hd / 2), m->rope_cos32 + (size_t)pos[r] * (hd / 2));
+        orc_rope_llama31(k + (size_t)r * KN, nkv, hd, m->rope_sin32 + (size_t)pos[r] * (hd / 2), m->rope_cos32 + (size_t)pos[r] * (hd / 2));
+      } else {
+        orc_rope(q + (size_t)r * QN, nq, hd, sn, cs);
+        orc_rope(k + (size_t)r * KN, nkv, hd, sn, cs);
+      }
       if (m->q_scalar != 0.0f && m->q_scalar != 1.0f)   /* attentions.py:2262-2264 */
         for (int i = 0; i < QN; ++i) q[(size_t)r * QN + i] = f2bf(bf2f(q[(size_t)r * QN + i]) * qsc);
       if (active[r]) {

@@ -57,6 +57,7 @@ class _CModel(ctypes.Structure):
       ("norm_logits", ctypes.c_int32), ("pan", _u16pp), ("pfn", _u16pp),
       ("qn", _u16pp), ("kn", _u16pp), ("q_scalar", ctypes.c_float), ("rope_sin_local", _u16p), ("rope_cos_local", _u16p),
       ("n_exp", ctypes.c_int32), ("top_k", ctypes.c_int32), ("gate", _u16pp),
+      ("rope_sin32", _f32p), ("rope_cos32", _f32p),
   ]
 
 
@@ -129,6 +130,27 @@ def rope_tables(head_dim: int, max_pos: int, min_timescale: float = 1.0, max_tim
   sn = np.sin(ang.astype(np.float64)).astype(np.float32)
   cs = np.cos(ang.astype(np.float64)).astype(np.float32)
   return f32_to_bf16(sn), f32_to_bf16(cs)
+
+
+def rope_tables_llama31(head_dim: int, max_pos: int, min_timescale: float = 1.0, max_timescale: float = 10000.0, use_scale: bool = True):
+  """LLaMARotaryEmbedding's sin / cos as f32 [max_pos][head_dim/2] (embeddings.py:396-443, :474-479): timescale of the pair (2i, 2i+1) as in
+  rope_tables; with use_scale the frequency 1 / timescale is kept for wavelengths below 8192 / 4, divided by 8 above 8192, blended
+  smoothly between (scale_factor 8, low / high frequency factors 1 / 4, original context 8192), all in f32; angle = f32(pos) / timescale;
+  sin / cos evaluated in f64 on the f32 angle and rounded to f32."""
+  half = head_dim // 2
+  frac = (2 * np.arange(half, dtype=np.int32)).astype(np.float32) / np.float32(head_dim)
+  ts = (np.float64(min_timescale) * np.power(np.float64(max_timescale) / np.float64(min_timescale), frac.astype(np.float64))).astype(np.float32)
+  if use_scale:
+    one, f32 = np.float32(1.0), np.float32
+    freq = one / ts
+    wavelen = f32(2.0) * f32(3.14159265358979323846) / freq
+    smooth = (f32(8192.0) / wavelen - f32(1.0)) / (f32(4.0) - f32(1.0))
+    blended = (one - smooth) * freq / f32(8.0) + smooth * freq
+    freq = np.where(wavelen < f32(8192.0) / f32(4.0), freq, np.where(wavelen > f32(8192.0) / f32(1.0), freq / f32(8.0), blended)).astype(np.float32)
+    ts = (one / freq).astype(np.float32)
+  pos = np.arange(max_pos, dtype=np.int32).astype(np.float32)
+  ang = (pos[:, None] / ts[None, :]).astype(np.float32)
+  return np.sin(ang.astype(np.float64)).astype(np.float32), np.cos(ang.astype(np.float64)).astype(np.float32)
 
 
 # ----------------------------------------------------------------------------- page manager
@@ -356,6 +378,8 @@ class OracleConfig:
   # Gemma-3 block (layers/gemma3.py:35-200; configs/models/gemma3-4b.yml): one (attention, MLP) pair per layer, layer i local unless
   # i % 6 == 5; query / key RMSNorm over head_dim; q * query_pre_attn_scalar after RoPE; the local layers' own RoPE base
   local_rope_max_timescale: float = -1.0
+  rope_type: str = "default"          # "llama3.1": LLaMARotaryEmbedding (embeddings.py:354-488)
+  rope_use_scale: bool = True
   query_pre_attn_scalar: float = 0.0
   # Mixtral block (layers/mixtral.py:52-170, layers/moe.py; configs/models/mixtral-8x7b.yml): the llama2 wiring with a routed mixture of
   # num_experts MLPs, num_experts_per_tok of them per token
@@ -489,6 +513,9 @@ class OracleModel:
       m.wout = arr([(lp % i + "mlp/wo/kernel", (F, E)) for i in range(L)])
     self.rope_sin, self.rope_cos = rope_tables(D, cfg.max_target_length, cfg.rope_min_timescale, cfg.rope_max_timescale)
     m.rope_sin, m.rope_cos = _p(self.rope_sin, _u16p), _p(self.rope_cos, _u16p)
+    if str(cfg.rope_type).lower().startswith("llama3.1"):
+      self.rope_sin32, self.rope_cos32 = rope_tables_llama31(D, cfg.max_target_length, cfg.rope_min_timescale, cfg.rope_max_timescale, bool(cfg.rope_use_scale))
+      m.rope_sin32, m.rope_cos32 = _p(self.rope_sin32, _f32p), _p(self.rope_cos32, _f32p)
     n = L * cfg.pagedattn_num_pages * cfg.pagedattn_tokens_per_page * KV * D
     self.kpages = np.zeros((n,), np.uint16)
     self.vpages = np.zeros((n,), np.uint16)

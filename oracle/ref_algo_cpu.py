@@ -61,8 +61,18 @@ class RefAlgoCPU:
     half = self.D // 2
     lo, hi = float(getattr(cfg, "rope_min_timescale", 1)), float(getattr(cfg, "rope_max_timescale", 10000))
     ts = (lo * ((hi / lo) ** (torch.arange(half, dtype=torch.float32) * 2 / self.D)))       # embeddings.py:254-268
+    self.llama31 = str(getattr(cfg, "rope_type", "default")).lower().startswith("llama3.1")
+    if self.llama31 and bool(getattr(cfg, "rope_use_scale", True)):      # embeddings.py:417-443
+      freq = 1.0 / ts
+      wavelen = 2 * torch.pi / freq
+      smooth = (8192.0 / wavelen - 1.0) / (4.0 - 1.0)
+      freq = torch.where(wavelen < 8192.0 / 4.0, freq, torch.where(wavelen > 8192.0, freq / 8.0, (1 - smooth) * freq / 8.0 + smooth * freq))
+      ts = 1.0 / freq
     ang = torch.arange(target_len, dtype=torch.float32)[:, None] / ts[None, :]
-    self.sin, self.cos = torch.sin(ang).to(torch.bfloat16), torch.cos(ang).to(torch.bfloat16)
+    if self.llama31:
+      self.sin, self.cos = torch.sin(ang), torch.cos(ang)                # f32 tables (embeddings.py:474-479)
+    else:
+      self.sin, self.cos = torch.sin(ang).to(torch.bfloat16), torch.cos(ang).to(torch.bfloat16)
     A = target_len - prefill_len
     z = lambda n: torch.zeros((self.L, batch, n, self.KV, self.D), dtype=torch.bfloat16)
     self.pk, self.pv, self.ak, self.av = z(prefill_len), z(prefill_len), z(A), z(A)      # cached_prefill_key/value, cached_ar_key/value
@@ -82,6 +92,15 @@ class RefAlgoCPU:
     return (y.float() * scale).to(torch.bfloat16)
 
   def _rope(self, x, pos):   # x [..., n, heads, D], pos [..., n]
+    if self.llama31:         # embeddings.py:446-488, written the reference's way: shifted copies, a parity select, a sign vector
+      s = self.sin[pos].unsqueeze(-2).repeat_interleave(2, dim=-1)
+      c = self.cos[pos].unsqueeze(-2).repeat_interleave(2, dim=-1)
+      left = torch.cat([x[..., 1:], x[..., :1]], -1)
+      right = torch.cat([x[..., -1:], x[..., :-1]], -1)
+      odd = (torch.arange(self.D) % 2).bool()
+      shifted = torch.where(odd, right, left)
+      sign = torch.tensor([-1.0, 1.0]).repeat(self.D // 2)
+      return (x.float() * c + shifted.float() * s * sign).to(torch.bfloat16)
     half = self.D // 2
     s, c = self.sin[pos].unsqueeze(-2), self.cos[pos].unsqueeze(-2)
     x1, x2 = x[..., :half], x[..., half:]

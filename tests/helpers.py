@@ -41,7 +41,7 @@ def oracle_config(cfg):
       sliding_window_size=int(cfg.sliding_window_size or 0), use_post_attn_norm=bool(cfg.use_post_attn_norm),
       use_post_ffw_norm=bool(cfg.use_post_ffw_norm), logits_via_embedding=bool(cfg.logits_via_embedding),
       normalize_embedding_logits=bool(cfg.normalize_embedding_logits),
-      local_rope_max_timescale=float(cfg.local_rope_max_timescale),
+      local_rope_max_timescale=float(cfg.local_rope_max_timescale), rope_type=str(cfg.rope_type), rope_use_scale=bool(cfg.rope_use_scale),
       query_pre_attn_scalar=float(maxengine_module().get_query_pre_attn_scalar(cfg)) if cfg.decoder_block == "gemma3" else 0.0)
 
 

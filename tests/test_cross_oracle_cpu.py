@@ -131,3 +131,18 @@ def test_dense_ring_wrap_agrees_with_pages():
     assert _close(ld, lo, LOGIT_TOL), f"step {step} (ring index {dense.ar_index}): max abs diff {np.abs(ld - lo).max()}"
     dense.tokens[1] = int(orr[0, 0])
   assert wrapped
+
+
+def test_llama31_rope_dense_restatement_agrees_with_paged_oracle():
+  """rope_type "llama3.1" (LLaMARotaryEmbedding, embeddings.py:354-488): the oracle rotates neighbouring pairs with an explicit per-pair formula,
+  the dense restatement writes the reference's shifted-copies / select / sign expression; same tolerances as above, frequency scaling on."""
+  cfg = H.make_config(per_device_batch_size=2.0, max_prefill_predict_length=32, max_target_length=80, pagedattn_num_pages=64, rope_type="llama3.1")
+  w = H.synth.synth_weights(cfg, 2)
+  prompts = [H.synth.synth_prompt(cfg.vocab_size, 32, 7), H.synth.synth_prompt(cfg.vocab_size, 32, 8)]
+  stats = _run_pair(cfg, w, prompts, 24)
+  _check(stats)
+  # and it is a different model from the default rotation: the first tokens' logits differ
+  cfg0 = H.make_config(per_device_batch_size=2.0, max_prefill_predict_length=32, max_target_length=80, pagedattn_num_pages=64)
+  a, _ = H.make_oracle(cfg, w).prefill(*prompts[0], slot=0, want_logits=True)
+  b, _ = H.make_oracle(cfg0, w).prefill(*prompts[0], slot=0, want_logits=True)
+  assert np.abs(a["logits"] - b["logits"]).max() > 1e-2
