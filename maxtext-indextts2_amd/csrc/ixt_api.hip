@@ -109,6 +109,8 @@ struct ixt_ctx {
   // block of k_sdot (0: by shape); small_attn_waves: waves per (row, kv head) block of k_attn_small (4: k_attn_decode instead)
   int small_rows = 16, small_tpb = 0, small_attn_waves = 16, small_attn_max_blocks = 512;
   int dot_small = 0;         // ixt_op_dot through k_sdot where it fits (tests)
+  int small_prefetch = 0;    // few-rows path: prefetch blocks stream the next launch's kernel into the Infinity Cache (ixt_prefetch).  Measured SLOWER (one utterance 1.19 against 1.03 ms per step, eight 1.33 against 1.23: a launch cannot end before its prefetch has, and an Infinity-Cache hit is only 1.4 x an HBM stream): off
+  int small_prefetch_blocks = 64;
   int small_norm = 1;        // 1: the RMSNorm in front of the QKV / wi projections runs inside k_sdot; 0: k_rownorm launches (experiments)
   int dot_stream_min_blocks = 1 << 30;   // off: measured slower than split-K at 256 rows (decode 7.84 vs 7.68 ms/step, prefill 3.53 vs 3.31 ms)
   ColRanges sample_cols{};   // greedy sampling restricted to these columns (n == 0: all)
@@ -1290,7 +1292,7 @@ static int launch_attention_partials(ixt_ctx* c, int layer, int R, int len_hint,
 }
 
 // ---- few rows: k_sdot / k_attn_small (ixt_small.h)
-struct SdotPlan { int chains, tpb, rpl; size_t lds; bool ok; };
+struct SdotPlan { int chains, tpb, rpl; size_t lds; bool ok; int pf_blocks; };
 static SdotPlan sdot_plan(const ixt_ctx* c, int epi, bool norm, int K, int N, int R) {
   SdotPlan p{};
   p.chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
@@ -1312,8 +1314,7 @@ static SdotPlan sdot_plan(const ixt_ctx* c, int epi, bool norm, int K, int N, in
 
 template <int EPI, bool NORM>
 static int sdot_t(const SdotArgs& a, const SdotPlan& p, hipStream_t st) {
-  const int ntile = a.N / 16;
-  hipLaunchKernelGGL((k_sdot<EPI, NORM>), dim3((ntile + p.tpb - 1) / p.tpb), dim3(64 * p.chains * p.tpb), p.lds, st, a);
+  hipLaunchKernelGGL((k_sdot<EPI, NORM>), dim3(a.main_blocks + (a.pf_n ? p.pf_blocks : 0)), dim3(64 * p.chains * p.tpb), p.lds, st, a);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -1332,12 +1333,17 @@ static int sdot_set_attributes() {
 
 // x: NORM: hidden rows [R][K] row-major (+ scale); else activations in xidx layout.  w: widx layout.
 static int launch_sdot(ixt_ctx* c, int epi, bool norm, const bf16_t* x, const bf16_t* scale, const bf16_t* w, int K, int N, int R, const GemmEpi& e,
-                       hipStream_t st) {
-  const SdotPlan p = sdot_plan(c, epi, norm, K, N, R);
+                       hipStream_t st, const bf16_t* pf = nullptr, size_t pf_elems = 0) {
+  SdotPlan p = sdot_plan(c, epi, norm, K, N, R);
   if (!p.ok) return set_err(IXT_ERR_UNSUPPORTED, "sdot: %d rows x K %d x N %d does not fit the few-rows form", R, K, N);
   SdotArgs a;
   a.x = x; a.scale = scale; a.eps = c->cfg.normalization_layer_epsilon; a.w = reinterpret_cast<const u32x4*>(w);
   a.K = K; a.N = N; a.R = R; a.rpl = p.rpl; a.tpb = p.tpb; a.chains = p.chains; a.e = e;
+  a.main_blocks = (N / 16 + p.tpb - 1) / p.tpb;
+  const bool prefetch = c->small_prefetch && pf != nullptr && pf_elems > 0;
+  a.pf = prefetch ? reinterpret_cast<const u32x4*>(pf) : nullptr;
+  a.pf_n = prefetch ? pf_elems / 8 : 0;
+  p.pf_blocks = c->small_prefetch_blocks;
   const int ti = timing_begin(c, st, (double)K * N * 2.0 + (double)R * K * 2.0);
   int rc = IXT_ERR_UNSUPPORTED;
   if (epi == GEPI_QKV) rc = norm ? sdot_t<GEPI_QKV, true>(a, p, st) : sdot_t<GEPI_QKV, false>(a, p, st);
@@ -1349,23 +1355,26 @@ static int launch_sdot(ixt_ctx* c, int epi, bool norm, const bf16_t* x, const bf
 }
 
 template <int HD, int GQ>
-static void launch_attn_small_t(ixt_ctx* c, int layer, int R, hipStream_t st) {
+static void launch_attn_small_t(ixt_ctx* c, int layer, int R, hipStream_t st, const bf16_t* pf, size_t pf_elems) {
   const AttnGeom& g = c->geom;
   DecAttnArgs da{};
+  const bool prefetch = c->small_prefetch && pf != nullptr && pf_elems > 0;
+  da.rows = R; da.pf = prefetch ? reinterpret_cast<const u32x4*>(pf) : nullptr; da.pf_n = prefetch ? pf_elems / 8 : 0;
+  const int pf_rows = prefetch ? (2 * c->small_prefetch_blocks + g.nkv - 1) / g.nkv : 0;   // (the attention leaves most of the chip idle: twice the blocks)
   da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
   da.rope_sin = c->rope_sin; da.rope_cos = c->rope_cos;
   da.kpages = c->kpages_l[layer]; da.vpages = c->vpages_l[layer];
   da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
   const size_t lds = sizeof(float) * ((size_t)GQ * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + 2 * ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * HD);
-  hipLaunchKernelGGL((k_attn_small<HD, GQ, 8>), dim3(g.nkv, R), dim3(512), lds, st, da);
+  hipLaunchKernelGGL((k_attn_small<HD, GQ, 8>), dim3(g.nkv, R + pf_rows), dim3(512), lds, st, da);
 }
 static bool attn_small_fits(const ixt_ctx* c, int R) {
   const AttnGeom& g = c->geom;
   const size_t lds = sizeof(float) * ((size_t)c->GQ * c->D + (size_t)c->GQ * ((g.Tmax + 3) & ~3) + 2 * ((g.mpg + 3) & ~3) + 16 + (size_t)g.nsb_max * c->D);
   return c->small_attn_waves >= 8 && (long)R * c->KV <= c->small_attn_max_blocks && lds <= 64 * 1024 && (c->D == 128 || c->D == 64) && (c->GQ == 1 || c->GQ == 2);   // (four query heads per kv head: the buffers spill)
 }
-static int launch_attn_small(ixt_ctx* c, int layer, int R, hipStream_t st) {
-#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn_small_t<HD_, GQ_>(c, layer, R, st); LAUNCHCHK(); return IXT_OK; }
+static int launch_attn_small(ixt_ctx* c, int layer, int R, hipStream_t st, const bf16_t* pf = nullptr, size_t pf_elems = 0) {
+#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn_small_t<HD_, GQ_>(c, layer, R, st, pf, pf_elems); LAUNCHCHK(); return IXT_OK; }
   ATT(128, 1) ATT(128, 2) ATT(64, 1) ATT(64, 2)
 #undef ATT
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
@@ -1532,8 +1541,9 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     GemmEpi e{};
     e.row_slot = c->row_slot; e.row_pos = c->row_pos; e.row_active = c->row_active; e.page_map = c->ps.page_map;
     e.rope_sin = c->rope_sin; e.rope_cos = c->rope_cos; e.qbuf = c->qbuf; e.kpages = c->kpages_l[l]; e.vpages = c->vpages_l[l]; e.g = c->geom;
+    const bf16_t* next_qkv = l + 1 < c->L ? c->layers[l + 1].wqkv : nullptr;
     if (c->small_norm) {
-      TRY(launch_sdot(c, GEPI_QKV, true, hcur, w.ln1, w.wqkv, E, c->NQKV, R, e, st));
+      TRY(launch_sdot(c, GEPI_QKV, true, hcur, w.ln1, w.wqkv, E, c->NQKV, R, e, st, w.wo, (size_t)c->QN * E));   // while QKV runs: the O kernel
     } else {
       TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hcur, nullptr, w.ln1, c->xn, st));
       TRY(launch_sdot(c, GEPI_QKV, false, c->xn, nullptr, w.wqkv, E, c->NQKV, R, e, st));
@@ -1541,7 +1551,7 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     {
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
       if (attn_small) {
-        TRY(launch_attn_small(c, l, R, st));
+        TRY(launch_attn_small(c, l, R, st, w.wi, (size_t)E * 2 * F));                                             // while the attention runs: the wi kernel
       } else if (fused_lds <= 64 * 1024) {
         TRY(launch_attention_fused(c, l, R, DotResult{0, 0, 0}, false, st));
       } else {
@@ -1557,7 +1567,7 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     GemmEpi eu{};
     eu.act = c->hact;
     if (c->small_norm) {
-      TRY(launch_sdot(c, GEPI_SWIGLU, true, hnext, w.ln2, w.wi, E, 2 * F, R, eu, st));
+      TRY(launch_sdot(c, GEPI_SWIGLU, true, hnext, w.ln2, w.wi, E, 2 * F, R, eu, st, w.wout, (size_t)F * E));      // while wi runs: the wo kernel
     } else {
       TRY(launch_rownorm(c, 2, R, nullptr, nullptr, hnext, nullptr, w.ln2, c->xn, st));
       TRY(launch_sdot(c, GEPI_SWIGLU, false, c->xn, nullptr, w.wi, E, 2 * F, R, eu, st));
@@ -1565,7 +1575,7 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     if (down_small) {
       GemmEpi ed{};
       ed.h_in = hnext; ed.h_out = hcur;
-      TRY(launch_sdot(c, GEPI_RESID, false, c->hact, nullptr, w.wout, F, E, R, ed, st));
+      TRY(launch_sdot(c, GEPI_RESID, false, c->hact, nullptr, w.wout, F, E, R, ed, st, next_qkv, (size_t)E * c->NQKV));   // while wo runs: the next layer's QKV kernel
     } else {   // R x mlp_dim activations beyond the LDS: split-K slices + slice-sum / residual
       DotResult dr;
       TRY(launch_dot(c, c->hact, w.wout, F, E, R, c->part, c->part_floats, false, st, &dr, true));
@@ -2087,7 +2097,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"moe_grouped", &c->moe_grouped, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

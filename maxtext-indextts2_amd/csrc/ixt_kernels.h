@@ -1169,6 +1169,8 @@ struct DecAttnArgs {
   bf16_t* out;        // [R][nq*hd] in xidx layout
   AttnGeom g;
   const bf16_t* qbuf; // NEWTOK = false: [R][nq][hd] finalised queries
+  int rows;           // k_attn_small: blocks with blockIdx.y >= rows are prefetch blocks
+  const u32x4* pf; size_t pf_n;
 };
 
 // NEWTOK = true: decode rows (the row's own new token is finalised here: QKV slices -> RoPE -> pages, and read back from LDS).

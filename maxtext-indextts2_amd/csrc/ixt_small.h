@@ -20,6 +20,22 @@
 // row depends on its own B column only).  ds_read_b128 of that pattern is conflict-free for every Rp (MI355X_MICROARCH.md, LDS).
 #pragma once
 
+// Weight prefetch (performance only, results untouched): extra blocks behind a launch's own grid stream the NEXT launch's kernel through the
+// memory hierarchy and throw the values away.  At few rows every launch of the layer is one burst of weight loads between a start-up and a
+// tail during which HBM idles (5 launches x ~5 us per layer against ~22 us of streaming); the prefetch blocks fill those gaps, and the next
+// launch finds its 8 - 60 MB in the 256 MB Infinity Cache (hit latency 227 ns against 375+ ns, 1.4 x the streaming rate: MI355X_MICROARCH.md).
+// Block b of nb takes the b-th slice; 8 loads of 16 bytes in flight per thread.
+__device__ __forceinline__ void ixt_prefetch(const u32x4* __restrict__ p, size_t n, int b, int nb, int tid, int nthr) {
+  const size_t lo = n * (size_t)b / (size_t)nb, hi = n * (size_t)(b + 1) / (size_t)nb;
+  for (size_t i = lo + tid; i < hi; i += (size_t)8 * nthr) {
+    u32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[min(i + (size_t)u * nthr, hi - 1)];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) asm volatile("" ::"v"(v[u].x), "v"(v[u].y), "v"(v[u].z), "v"(v[u].w));   // the loads must complete; nothing is kept
+  }
+}
+
 struct SdotArgs {
   const bf16_t* x;       // NORM = false: [K/8][16][8] (xidx layout, row block 0); NORM = true: hidden rows [R][K] row-major
   const bf16_t* scale;   // NORM: RMSNorm scale [K]
@@ -27,12 +43,17 @@ struct SdotArgs {
   const u32x4* w;        // widx layout
   int K, N, R, rpl, tpb, chains;
   GemmEpi e;
+  const u32x4* pf; size_t pf_n; int main_blocks;   // prefetch: blocks main_blocks .. gridDim.x - 1 stream pf[0 .. pf_n) (16-byte units)
 };
 
 template <int EPI, bool NORM>
 __global__ __launch_bounds__(1024) void k_sdot(SdotArgs a) {
   extern __shared__ __attribute__((aligned(16))) u32x4 sx[];
   const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63;
+  if ((int)blockIdx.x >= a.main_blocks) {        // a prefetch block (whole block: no barrier is skipped)
+    ixt_prefetch(a.pf, a.pf_n, (int)blockIdx.x - a.main_blocks, (int)gridDim.x - a.main_blocks, tid, nthr);
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform by construction: keeps (tile, chain) and every branch on them scalar
   const int K = a.K, N = a.N, R = a.R, tpb = a.tpb, chains = a.chains;
   const int nsteps = K >> 5, ntile = N >> 4, nch = K >> 3;
@@ -265,6 +286,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
   const AttnGeom& g = a.g;
   const int kvh = blockIdx.x, r = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63;
+  if (r >= a.rows) {                               // prefetch blocks behind the rows' blocks (ixt_prefetch)
+    ixt_prefetch(a.pf, a.pf_n, (r - a.rows) * (int)gridDim.x + kvh, ((int)gridDim.y - a.rows) * (int)gridDim.x, tid, NT);
+    return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n_out = g.nq * HD;
   if (!a.row_active[r]) {

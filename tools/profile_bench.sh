@@ -5,7 +5,7 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 export TMPDIR=/tmp
-(cd /tmp && timeout -k 10 ${PROF_TIMEOUT:-500} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch-rows --no-roofline --no-detail --sync-every 16 "$@" > $OUT/run.txt 2>&1)
+(cd /tmp && timeout -k 10 ${PROF_TIMEOUT:-500} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 $REPO/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-batch-rows --no-big-rows --no-roofline --no-detail --sync-every 16 "$@" > $OUT/run.txt 2>&1)
 echo "rocprofv3 rc=$?" >> $OUT/run.txt
 T=$(find $OUT -name '*kernel_trace.csv' | head -1); S=$(find $OUT -name '*kernel_stats.csv' | head -1)
 python3 tools/summarize_trace.py $T > gpurun_out/prof_by_grid.txt
