@@ -432,8 +432,9 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   if (x->fp8) {
     if (moe && c.ep_size > 1) return fail(set_err(IXT_ERR_UNSUPPORTED, "fp8 weights with expert-sharded contexts are not built"));
     const int kmax8 = F > x->QN ? (F > E ? F : E) : (x->QN > E ? x->QN : E);
-    A(dmalloc(x, &x->x8, Rp * (size_t)kmax8));
-    A(dmalloc(x, &x->xs8, Rp * (size_t)((kmax8 + IXT_CHAIN - 1) / IXT_CHAIN)));
+    const size_t rows8 = std::max(Rp, (size_t)x->moe_rows_cap);     // the routed experts quantise their copy rows (incl. alignment padding)
+    A(dmalloc(x, &x->x8, rows8 * (size_t)kmax8));
+    A(dmalloc(x, &x->xs8, rows8 * (size_t)((kmax8 + IXT_CHAIN - 1) / IXT_CHAIN)));
     auto twin = [&](const bf16_t* w, int K_, int N_) -> int {
       ixt_ctx::F8W t{nullptr, nullptr, K_, N_};
       int r = dmalloc(x, &t.w8, (size_t)K_ * N_);
@@ -445,8 +446,15 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
       LayerW& w = x->layers[i];
       A(twin(w.wqkv, E, x->NQKV));
       A(twin(w.wo, x->QN, E));
-      if (moe) {
-        for (int e = 0; e < x->NEL; ++e) { A(twin(w.ewi[e], E, 2 * F)); A(twin(w.ewout[e], F, E)); }
+      if (moe) {   // all experts' twins of a layer in one allocation each, fixed strides apart (the routed launches index them by expert on the device)
+        uint8_t *wi8 = nullptr, *wo8 = nullptr;
+        float *si = nullptr, *so = nullptr;
+        A(dmalloc(x, &wi8, (size_t)x->NEL * E * 2 * F)); A(dmalloc(x, &wo8, (size_t)x->NEL * F * E));
+        A(dmalloc(x, &si, (size_t)x->NEL * 2 * F)); A(dmalloc(x, &so, (size_t)x->NEL * E));
+        for (int e = 0; e < x->NEL; ++e) {
+          x->f8w[w.ewi[e]] = ixt_ctx::F8W{wi8 + (size_t)e * E * 2 * F, si + (size_t)e * 2 * F, E, 2 * F};
+          x->f8w[w.ewout[e]] = ixt_ctx::F8W{wo8 + (size_t)e * F * E, so + (size_t)e * E, F, E};
+        }
       } else {
         A(twin(w.wi, E, 2 * F));
         A(twin(w.wout, F, E));
@@ -1487,6 +1495,38 @@ static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, cons
   hipLaunchKernelGGL(k_moe_gather, dim3((E + 2047) / 2048, npairs), dim3(256), 0, st, x, c->moe_pos, top_k, E, c->moe_xg);
   LAUNCHCHK();
   const size_t wi_stride = c->moe_wi_stride / 8, wo_stride = c->moe_wo_stride / 8;   // 16-byte units
+  if (c->fp8) {   // IXT-FP8-v1: the experts' e4m3 twins (contiguous per layer), activations quantised per copy row and 512-k block
+    const ixt_ctx::F8W &ti = c->f8w.at(w.ewi[0]), &to = c->f8w.at(w.ewout[0]);
+    auto dot8g = [&](const bf16_t* xin, const ixt_ctx::F8W& t, int K, int N, size_t sstride) -> int {
+      const int chains = (K + IXT_CHAIN - 1) / IXT_CHAIN;
+      hipLaunchKernelGGL(k_f8_quant_x, dim3(chains, rows_g / 16), dim3(64), 0, st, xin, K, rows_g, c->x8, c->xs8);
+      const size_t w8stride = (size_t)K * N / 16;              // bytes / 16
+      if (align == 16) {
+        if ((size_t)chains * rows_g * N > c->part_floats) return set_err(IXT_ERR_INVALID, "moe: slice workspace too small");
+        const int nwaves = N / 16, zblocks = rows_g / 16;
+        const int ti_ = timing_begin(c, st, (double)K * N * c->NEL + (double)rows_g * K + (double)chains * rows_g * N * 4.0);
+        dim3 grid((((nwaves + 3) / 4 + 7) / 8) * 8 * zblocks, chains, 1);
+        hipLaunchKernelGGL((k_dotb8<1>), grid, dim3(256), (size_t)8192, st, reinterpret_cast<const u32x4*>(c->x8), reinterpret_cast<const u32x4*>(t.w8), c->xs8, t.s, K, N,
+                           rows_g, c->part, nwaves, zblocks, c->moe_rbexp, w8stride, sstride);
+        timing_end(c, st, ti_);
+        LAUNCHCHK();
+        return chains;
+      }
+      if ((size_t)rows_g * N > c->part_floats) return set_err(IXT_ERR_INVALID, "moe: output workspace too small");
+      GemmEpi e{};
+      e.out = c->part; e.xscale = c->xs8; e.wscale = t.s; e.sstride = sstride; e.rb_exp = c->moe_rbexp; e.wstride = w8stride;
+      const int rc = ring_launch8_t<2, 4, 4, 2, 2, 4>(c->x8, t.w8, K, N, rows_g, e, st);
+      return rc == IXT_OK ? 1 : rc;
+    };
+    int ch = dot8g(c->moe_xg, ti, E, 2 * F, (size_t)2 * F);
+    if (ch < 0) return ch;
+    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, rows_g), dim3(256), 0, st, c->part, ch, (size_t)rows_g * 2 * F, F, c->moe_hact, c->moe_rbexp);
+    LAUNCHCHK();
+    ch = dot8g(c->moe_hact, to, F, E, (size_t)E);
+    if (ch < 0) return ch;
+    res->slices = ch; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
+    return IXT_OK;
+  }
   if (align == 16) {
     const int zblocks = rows_g / 16;
     auto dotg = [&](const bf16_t* xin, const bf16_t* wbase, size_t wstride, int K, int N) -> int {
@@ -1690,7 +1730,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
       hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
       LAUNCHCHK();
-      if (c->moe_grouped && !c->fp8) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
+      if (c->moe_grouped) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
         DotResult mr;
         TRY(moe_experts_routed(c, w, c->xn, c->moe_idx, R * c->TK, c->TK, st, &mr));
         hipLaunchKernelGGL(k_moe_combine_rows, dim3((E + 255) / 256, R), dim3(256), 0, st, c->part, mr.slices, mr.slice_stride, c->moe_pos, c->moe_w, E, c->TK, c->moe_comb);

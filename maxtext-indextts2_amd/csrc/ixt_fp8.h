@@ -88,9 +88,12 @@ __global__ __launch_bounds__(64) void k_f8_quant_x(const bf16_t* __restrict__ x 
 // ---- the dot below 128 rows: k_dotb's split-K form on e4m3 fragments.  grid = (tile groups x row-block groups, chains), block 256 (4 waves =
 //      4 adjacent 16-column tiles), LDS = NRB x 8 KiB.  Every wave issues the 8 weight fragments of its chain (8 KiB in flight per wave), the block
 //      copies the chain's activation fragments to LDS once; 16 x NRB MFMAs; the accumulator times (a_rc s_n) is slice c.
+//      Routed experts (rb_exp != nullptr; NRB = 1), as in k_dotb: row block rb belongs to expert rb_exp[rb], whose e4m3 kernel starts wstride 16-byte
+//      units after w8 and whose column scales start sstride floats after wscale; a row block of no expert leaves at once.
 template <int NRB>
 __global__ __launch_bounds__(256, 2) void k_dotb8(const u32x4* __restrict__ x8, const u32x4* __restrict__ w8, const float* __restrict__ xscale,
-                                                  const float* __restrict__ wscale, int K, int N, int R, float* __restrict__ out, int nwaves, int zblocks) {
+                                                  const float* __restrict__ wscale, int K, int N, int R, float* __restrict__ out, int nwaves, int zblocks,
+                                                  const int32_t* __restrict__ rb_exp = nullptr, size_t wstride = 0, size_t sstride = 0) {
   extern __shared__ __attribute__((aligned(16))) u32x4 xs[];   // [NRB][8 fragments][64 lanes]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -102,6 +105,12 @@ __global__ __launch_bounds__(256, 2) void k_dotb8(const u32x4* __restrict__ x8, 
   const int f0 = c * 8, cf = min(8, nfr - f0);                 // (K % 64 == 0: a last chain of 256 k has 4 fragments)
   const int r_in = lane & 15, cq = lane >> 4;
   const bool tile_ok = tile < nwaves;
+  if (rb_exp != nullptr) {
+    const int ex = rb_exp[rb0];
+    if (ex < 0) return;                                        // the whole block: no barrier is skipped
+    w8 += (size_t)ex * wstride;
+    wscale += (size_t)ex * sstride;
+  }
   // activation fragments of this chain first (L2), then the weights (HBM): loads return in order
   u32x4 xq[NRB * 2];
 #pragma unroll

@@ -39,6 +39,7 @@ struct GemmEpi {
   bf16_t* qbuf; bf16_t* kpages; bf16_t* vpages;
   AttnGeom g;
   const float* xscale; const float* wscale;             // F8: activation scales [rows][chains], column scales [N] (ixt_fp8.h)
+  size_t sstride;                                       // F8 + routed experts: floats between two experts' column scales
   const int32_t* rb_exp; size_t wstride;                // routed experts: expert of every 16-row block (-1: none), 16-byte units between experts' kernels
 };
 
@@ -73,6 +74,7 @@ __global__ __launch_bounds__(WR * WC * 64, 2) void k_gemm_ring(const u32x4* __re
     const int ex = (rowg * (WR * RB) < ((R + 15) >> 4)) ? e.rb_exp[rowg * (WR * RB)] : -1;
     if (ex < 0) return;
     wt += (size_t)ex * e.wstride;
+    if constexpr (F8) e.wscale += (size_t)ex * e.sstride;       // the expert's column scales
   }
   const int nsteps = F8 ? K >> 6 : K >> 5, ntile = N >> 4, nrbk = (R + 15) >> 4;   // fragments along k
   const int nchunks = nsteps / KS;
