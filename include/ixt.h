@@ -153,6 +153,11 @@ int ixt_pages_status(ixt_ctx* ctx, int32_t* out4, int reset, void* stream);
 /* The same four words copied to PINNED host memory in stream order, without waiting: the caller records an event behind the call and reads
  * the words once it has completed (a throughput path checks the reservations of packed prefill N while pass N already runs). */
 int ixt_pages_status_async(ixt_ctx* ctx, int32_t* host_out4, void* stream);
+/* Few decode rows: the keys of a (row, kv head) are split over several thread blocks that exchange their softmax statistics through HBM
+ * inside one launch (k_attn_split; option small_attn_split).  Their waits are bounded; out1 (HOST) = 1 if a wait ever gave up since the last
+ * reset (the affected step's numbers are then wrong -- the reference has no counterpart: its generate step, maxengine.py:838-935, is one XLA
+ * program), 0 otherwise.  Synchronises `stream`; reset != 0 re-arms the exchange. */
+int ixt_exchange_status(ixt_ctx* ctx, int32_t* out1, int reset, void* stream);
 /* Copy the seven PageState fields to HOST arrays (synchronises `stream`); the decode slots' groups only:
  * page_status[num_pages], page_map[max_slots*max_pages_per_group], num_pages_used[max_slots],
  * sequence_lengths[max_slots], active_page[max_slots], has_active_page[max_slots] (0/1),

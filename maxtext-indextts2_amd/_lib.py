@@ -60,6 +60,7 @@ SIGNATURES = {
     "ixt_pages_copy": (ctypes.c_int, [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp]),
     "ixt_pages_status": (ctypes.c_int, [vp, c_i32p, ctypes.c_int, vp]),
     "ixt_pages_status_async": (ctypes.c_int, [vp, vp, vp]),
+    "ixt_exchange_status": (ctypes.c_int, [vp, c_i32p, ctypes.c_int, vp]),
     "ixt_prefill_prompt_logp": (ctypes.c_int, [vp, vp, ctypes.c_int, vp, vp]),
     "ixt_build_id": (ctypes.c_char_p, []),
     "ixt_prefill_rows": (ctypes.c_int, [vp, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, vp, vp, vp, vp]),

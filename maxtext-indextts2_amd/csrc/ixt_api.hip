@@ -109,6 +109,13 @@ struct ixt_ctx {
   // block of k_sdot (0: by shape); small_attn_waves: waves per (row, kv head) block of k_attn_small (4: k_attn_decode instead)
   int small_rows = 16, small_tpb = 0, small_attn_waves = 16, small_attn_max_blocks = 512;
   int dot_small = 0;         // ixt_op_dot through k_sdot where it fits (tests)
+  // few rows: the keys of a (row, kv head) split over `S` blocks of k_attn_split (S = min(small_attn_split, 256 / (rows * kv heads)); < 2: k_attn_small)
+  int small_attn_split = 16;
+  int split_capacity = -1;   // blocks of k_attn_split the chip holds at once (occupancy query, once)
+  int moe_route_blocks = 1;  // router: one wave per 512-k block, all experts at once (0: one wave per expert)
+  int32_t* split_cnt = nullptr;   // [16][KV][4] arrival counters (zero between launches) + the error word behind them
+  float* split_ws = nullptr;      // [16][KV][split_stride]
+  size_t split_stride = 0;
   int small_prefetch = 0;    // few-rows path: prefetch blocks stream the next launch's kernel into the Infinity Cache (ixt_prefetch).  Measured SLOWER (one utterance 1.19 against 1.03 ms per step, eight 1.33 against 1.23: a launch cannot end before its prefetch has, and an Infinity-Cache hit is only 1.4 x an HBM stream): off
   int small_prefetch_blocks = 64;
   int small_norm = 1;        // 1: the RMSNorm in front of the QKV / wi projections runs inside k_sdot; 0: k_rownorm launches (experiments)
@@ -399,6 +406,13 @@ extern "C" int ixt_create(const ixt_config* cfg, ixt_ctx** out) {
   const size_t Rp = (size_t)((R + 15) / 16) * 16;  // k-major activations are padded to whole 16-row blocks
   A(dmalloc(x, &x->xn, Rp * E));
   A(dmalloc(x, &x->qbuf, (size_t)R * x->QN));
+  {
+    const int mpgp = (x->mpg + 3) & ~3;
+    x->split_stride = (size_t)x->GQ * 16 + (size_t)x->GQ * mpgp + (size_t)x->GQ * x->nsb_max * x->D;
+    A(dmalloc(x, &x->split_cnt, (size_t)16 * x->KV * 4 + 64));
+    A(dmalloc(x, &x->split_ws, (size_t)16 * x->KV * x->split_stride));
+    HIPCHK(hipMemset(x->split_cnt, 0, sizeof(int32_t) * ((size_t)16 * x->KV * 4 + 64)));
+  }
   A(dmalloc(x, &x->ao, Rp * x->QN));
   A(dmalloc(x, &x->hact, Rp * F));
   {
@@ -721,6 +735,15 @@ extern "C" int ixt_pages_status(ixt_ctx* c, int32_t* out4, int reset, void* stre
   HIPCHK(hipMemcpyAsync(out4, c->ps.status, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   if (reset) HIPCHK(hipMemsetAsync(c->ps.status, 0, sizeof(int32_t) * 4, st));
+  return IXT_OK;
+}
+extern "C" int ixt_exchange_status(ixt_ctx* c, int32_t* out1, int reset, void* stream) {
+  if (!c || !out1) return set_err(IXT_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  int32_t* err = c->split_cnt + (size_t)16 * c->KV * 4;
+  HIPCHK(hipMemcpyAsync(out1, err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  if (reset && *out1 != 0) HIPCHK(hipMemsetAsync(c->split_cnt, 0, sizeof(int32_t) * ((size_t)16 * c->KV * 4 + 4), st));   // a wait that gave up leaves its counters armed
   return IXT_OK;
 }
 extern "C" int ixt_pages_status_async(ixt_ctx* c, int32_t* host_out4, void* stream) {
@@ -1388,6 +1411,73 @@ static int launch_attn_small(ixt_ctx* c, int layer, int R, hipStream_t st, const
   return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
 }
 
+// Router: one wave per 512-k block over all experts when the expert count allows whole 16-byte gate loads and E fits the block table.
+static void launch_moe_route(ixt_ctx* c, int R, const bf16_t* xn, const bf16_t* gate, int32_t* idx, float* wts, hipStream_t st) {
+  const int nblk = (c->E / 8 + 63) / 64;
+  if (c->moe_route_blocks && nblk <= 64 && (c->NE == 8 || c->NE == 16)) {
+    const dim3 blk(64 * std::min(nblk, 16));
+    if (c->NE == 8) hipLaunchKernelGGL((k_moe_route_blocks<1>), dim3(R), blk, 0, st, xn, gate, c->E, c->TK, idx, wts);
+    else hipLaunchKernelGGL((k_moe_route_blocks<2>), dim3(R), blk, 0, st, xn, gate, c->E, c->TK, idx, wts);
+    return;
+  }
+  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, xn, gate, c->E, c->NE, c->TK, idx, wts);
+}
+
+// k_attn_split: S blocks per (row, kv head).  Every block of the launch must be resident at once (the waits need it): no more blocks than
+// the occupancy of THIS kernel instantiation with its LDS says fit the chip, and at most two per CU.
+template <int HD, int GQ>
+static int attn_split_capacity_t(size_t lds) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_attn_split<HD, GQ>, 256, lds) != hipSuccess) return 0;
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  return std::min(per_cu, 2) * cus;
+}
+static int attn_split_capacity(ixt_ctx* c, size_t lds) {
+  if (c->split_capacity >= 0) return c->split_capacity;
+  int cap = 0;
+#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) cap = attn_split_capacity_t<HD_, GQ_>(lds);
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4) ATT(256, 1) ATT(256, 2) ATT(256, 4)
+#undef ATT
+  c->split_capacity = cap;
+  return cap;
+}
+static int attn_split_factor(ixt_ctx* c, int R) {
+  const AttnGeom& g = c->geom;
+  if (c->small_attn_split < 2 || R > 16 || g.P > 32 || !(c->D == 256 || c->D == 128 || c->D == 64) || !(c->GQ == 1 || c->GQ == 2 || c->GQ == 4)) return 1;
+  const size_t lds = sizeof(float) * ((size_t)c->GQ * c->D + (size_t)c->GQ * ((g.Tmax + 3) & ~3) + ((g.mpg + 3) & ~3) + 32 + (size_t)c->GQ * 4 * c->D + (size_t)c->GQ * ((g.mpg + 3) & ~3));
+  if (lds > 64 * 1024) return 1;
+  // Where k_attn_small applies (plain scores, <= 2 query heads per kv head, head_dim <= 128) the two are level at the benchmark's model -- one
+  // utterance 1.069 against 1.046 ms per step, eight 1.318 against 1.229: the three exchanges cost ~3.5 us each, what the split saves in loads --,
+  // so the split form serves the geometries that one-block form does not hold: four query heads per kv head, head_dim 256, soft cap, window.
+  if (!c->gemma && c->small_attn_split < 100 && attn_small_fits(c, R)) return 1;
+  int S = attn_split_capacity(c, lds) / (R * c->KV);
+  const int smax = c->small_attn_split >= 100 ? c->small_attn_split - 100 : c->small_attn_split;   // 100 + S: also where k_attn_small would do (tests)
+  if (S > smax) S = smax;
+  if (S > 16) S = 16;
+  return S < 2 ? 1 : S;
+}
+template <int HD, int GQ>
+static void launch_attn_split_t(ixt_ctx* c, int layer, int R, int S, hipStream_t st, float cap, int window) {
+  const AttnGeom& g = c->geom;
+  DecAttnArgs da{};
+  da.rows = R;
+  da.row_slot = c->row_slot; da.row_pos = c->row_pos; da.row_active = c->row_active; da.page_map = c->ps.page_map;
+  da.kpages = c->kpages_l[layer]; da.vpages = c->vpages_l[layer];
+  da.out = c->ao; da.g = g; da.qbuf = c->qbuf;
+  SplitWs w{};
+  w.cnt = c->split_cnt; w.ws = c->split_ws; w.stride = c->split_stride; w.err = c->split_cnt + (size_t)16 * c->KV * 4; w.mpgp = (g.mpg + 3) & ~3;
+  w.cap = cap; w.window = window;
+  const size_t lds = sizeof(float) * ((size_t)GQ * HD + (size_t)GQ * ((g.Tmax + 3) & ~3) + w.mpgp + 32 + (size_t)GQ * 4 * HD + (size_t)GQ * w.mpgp);
+  hipLaunchKernelGGL((k_attn_split<HD, GQ>), dim3(g.nkv, R, S), dim3(256), lds, st, da, w);
+}
+static int launch_attn_split(ixt_ctx* c, int layer, int R, int S, hipStream_t st, float cap = 0.0f, int window = 0) {
+#define ATT(HD_, GQ_) if (c->D == HD_ && c->GQ == GQ_) { launch_attn_split_t<HD_, GQ_>(c, layer, R, S, st, cap, window); LAUNCHCHK(); return IXT_OK; }
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4) ATT(256, 1) ATT(256, 2) ATT(256, 4)
+#undef ATT
+  return set_err(IXT_ERR_UNSUPPORTED, "attention geometry hd=%d gq=%d", c->D, c->GQ);
+}
+
 // decoders.py:552-565 on nl rows of f32 logits in place (/ sqrt(emb), soft cap), then the greedy choice over the allowed columns of the
 // post-processed values (the cap is not strictly monotone after rounding, so the maximum is taken after it).
 static int launch_logits_post(ixt_ctx* c, float* lg, int nl, int normalize, float cap, int32_t* argmax_out, hipStream_t st) {
@@ -1435,13 +1525,18 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
     qa.q_scalar = (cf.query_pre_attn_scalar != 0.0f && cf.query_pre_attn_scalar != 1.0f) ? host_rbf(cf.query_pre_attn_scalar) : 0.0f;
     hipLaunchKernelGGL(k_qkv_finalize, dim3(R, c->Q + 2 * c->KV), dim3(64), 0, st, qa);
     LAUNCHCHK();
-    c->pv_cap = cf.attn_logits_soft_cap;
-    c->pv_window = local ? cf.sliding_window_size : 0;
-    int rc = launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st);
-    c->pv_cap = 0.0f; c->pv_window = 0;
-    TRY(rc);
-    hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
-    LAUNCHCHK();
+    const int attn_split = attn_split_factor(c, R);   // few rows (decode): the keys of a head over several blocks of ONE launch instead of scores / PV / combine
+    if (attn_split > 1) {
+      TRY(launch_attn_split(c, l, R, attn_split, st, cf.attn_logits_soft_cap, local ? cf.sliding_window_size : 0));
+    } else {
+      c->pv_cap = cf.attn_logits_soft_cap;
+      c->pv_window = local ? cf.sliding_window_size : 0;
+      int rc = launch_attention_partials(c, l, R, len_hint, DotResult{0, 0, 0}, false, st);
+      c->pv_cap = 0.0f; c->pv_window = 0;
+      TRY(rc);
+      hipLaunchKernelGGL(k_attn_combine, dim3(R), dim3(256), 0, st, c->pvpart, c->row_pos, c->row_active, c->ao, c->geom, 1);
+      LAUNCHCHK();
+    }
     TRY(launch_dot(c, c->ao, w.wo, c->QN, E, R, c->part, c->part_floats, false, st, &dr));
     GNormArgs ga;
     ga.part = c->part; ga.slices = dr.slices; ga.slice_stride = dr.slice_stride; ga.h_in = hcur; ga.h_out = hnext;
@@ -1574,6 +1669,7 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
   bf16_t* hnext = c->h_b;
   const bool down_small = sdot_plan(c, GEPI_RESID, false, F, E, R).ok;
   const bool attn_small = attn_small_fits(c, R);
+  const int attn_split = decode ? attn_split_factor(c, R) : 1;
   const size_t fused_lds = sizeof(float) * ((size_t)c->GQ * c->D + 2 * c->D + (size_t)c->GQ * (c->geom.Tmax + 3) + c->geom.mpg + 12 + (size_t)c->geom.nsb_max * c->D);
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, nullptr, nullptr, st));   // hidden rows = embedding rows (no norm: the QKV kernel norms)
   for (int l = 0; l < c->L; ++l) {
@@ -1590,7 +1686,9 @@ static int forward_rows_small(ixt_ctx* c, int R, const int32_t* tokens, int len_
     }
     {
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;
-      if (attn_small) {
+      if (attn_split > 1) {
+        TRY(launch_attn_split(c, l, R, attn_split, st));
+      } else if (attn_small) {
         TRY(launch_attn_small(c, l, R, st, w.wi, (size_t)E * 2 * F));                                             // while the attention runs: the wi kernel
       } else if (fused_lds <= 64 * 1024) {
         TRY(launch_attention_fused(c, l, R, DotResult{0, 0, 0}, false, st));
@@ -1699,7 +1797,8 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       continue;
     }
     TRY(launch_dot(c, c->xn, w.wqkv, E, c->NQKV, R, c->part, c->part_floats, false, st, &dr));
-    if (!decode) {
+    const int attn_split = decode && !attn_tiled ? attn_split_factor(c, R) : 1;   // few decode rows: finalise first, then the keys of a head over several blocks
+    if (!decode || attn_split > 1) {
       QkvArgs qa;
       qa.part = c->part; qa.slices = dr.slices; qa.slice_stride = dr.slice_stride; qa.ncols = c->NQKV;
       qa.row_slot = c->row_slot; qa.row_pos = c->row_pos; qa.row_active = c->row_active; qa.page_map = c->ps.page_map;
@@ -1712,6 +1811,10 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
     // one block per (row, kv head) once that fills the chip; below that the key range is split over blocks (3 launches)
     if (attn_tiled) {
       TRY(launch_attention_tile(c, l, R, len_hint, st));
+    } else if (attn_split > 1) {
+      const int ta = timing_begin(c, st, 0.0, 1);
+      TRY(launch_attn_split(c, l, R, attn_split, st));
+      timing_end(c, st, ta);
     } else if (attn_one_launch) {   // decode rows, and prefill rows after k_qkv_finalize
       const int ta = decode ? timing_begin(c, st, 0.0, 1) : -1;   // K/V bytes depend on the rows' lengths: the caller prices them
       TRY(launch_attention_fused(c, l, R, dr, decode, st));
@@ -1728,7 +1831,7 @@ static int forward_rows(ixt_ctx* c, int R, const int32_t* tokens, int len_hint, 
       // output does not depend on which other rows share its launch, so this equals the routed (permute / gmm / unpermute) form bit for
       // bit; it reads each expert's kernels once per pass, which is what decode with >= ~16 rows needs anyway, and spends
       // num_experts / num_experts_per_tok times the matrix-core work of the routed form on prefill (not yet built as a grouped GEMM).
-      hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xn, w.gate, E, c->NE, c->TK, c->moe_idx, c->moe_w);
+      launch_moe_route(c, R, c->xn, w.gate, c->moe_idx, c->moe_w, st);
       LAUNCHCHK();
       if (c->moe_grouped) {   // only the routed work: every copy in the rows of its expert, unselected experts never read
         DotResult mr;
@@ -1968,7 +2071,7 @@ extern "C" int ixt_op_moe_route(ixt_ctx* c, int layer, const uint16_t* x, int R,
   if (!x || !experts_out || !weights_out || R <= 0) return set_err(IXT_ERR_INVALID, "bad argument");
   hipStream_t st = (hipStream_t)stream;
   TRY(transpose_rows(c, x, R, c->E, st));
-  hipLaunchKernelGGL(k_moe_route, dim3(R), dim3(64 * std::min(c->NE, 16)), 0, st, c->xt_op, c->layers[layer].gate, c->E, c->NE, c->TK, experts_out, weights_out);
+  launch_moe_route(c, R, c->xt_op, c->layers[layer].gate, experts_out, weights_out, st);
   LAUNCHCHK();
   return IXT_OK;
 }
@@ -2137,7 +2240,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0}, {"small_attn_split", &c->small_attn_split, 0}, {"moe_route_blocks", &c->moe_route_blocks, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

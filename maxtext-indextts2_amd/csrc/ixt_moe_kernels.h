@@ -64,6 +64,76 @@ __global__ __launch_bounds__(1024) void k_moe_route(const bf16_t* xn, const bf16
   for (int j = 0; j < top_k; ++j) w_out[(size_t)r * top_k + j] = rbf(ex[j] / s);
 }
 
+// The same router with the work turned round (n_exp a multiple of 8): one wave per BLOCK of 512 k, all experts at once.  A lane's 8 k of the
+// gate kernel are 8 n_exp consecutive bf16 (row-major [E][n_exp]): whole 16-byte loads, consecutive lanes on consecutive lines -- k_moe_route
+// reads the same bytes two at a time, once per expert wave (21.5 us per launch at 4096 x 8; this form: see DESIGN.md section 10).  The order is the
+// contract's: a lane's 8 k by fma, xor tree over the wave, then the blocks' sums added in block order by one thread per expert.
+// grid = R, block = 64 min(blocks, 16).
+template <int NG>   // NG = n_exp / 8
+__global__ __launch_bounds__(1024) void k_moe_route_blocks(const bf16_t* xn, const bf16_t* gate, int E, int top_k, int32_t* idx_out, float* w_out) {
+  constexpr int NEXP = NG * 8;
+  __shared__ float part[64][NEXP];     // [block of 512 k][expert]
+  __shared__ float gl[NEXP];
+  const int r = blockIdx.x, lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nch = E / 8, nblk = (nch + 63) / 64;
+  for (int b = wave; b < nblk; b += nw) {
+    const int ch = b * 64 + lane;
+    const bool live = ch < nch;
+    const int chc = min(ch, nch - 1);
+    const u32x4 xv = *reinterpret_cast<const u32x4*>(xn + xidx(r, chc * 8, E));
+    u32x4 gv[8][NG];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int gq = 0; gq < NG; ++gq) gv[j][gq] = *reinterpret_cast<const u32x4*>(gate + (size_t)(chc * 8 + j) * NEXP + gq * 8);
+    const float x[8] = {bflo(xv.x), bfhi(xv.x), bflo(xv.y), bfhi(xv.y), bflo(xv.z), bfhi(xv.z), bflo(xv.w), bfhi(xv.w)};
+    float a[NEXP];
+#pragma unroll
+    for (int e = 0; e < NEXP; ++e) a[e] = 0.0f;
+    if (live) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+#pragma unroll
+        for (int gq = 0; gq < NG; ++gq) {
+          const u32x4 gw = gv[j][gq];
+          const float gf[8] = {bflo(gw.x), bfhi(gw.x), bflo(gw.y), bfhi(gw.y), bflo(gw.z), bfhi(gw.z), bflo(gw.w), bfhi(gw.w)};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[gq * 8 + e] = __builtin_fmaf(x[j], gf[e], a[gq * 8 + e]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < NEXP; ++e) {
+      float t = a[e];
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) t = t + __shfl_xor(t, off, 64);
+      if (lane == 0) part[b][e] = t;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < NEXP) {
+    float total = 0.0f;
+    for (int b = 0; b < nblk; ++b) total = total + part[b][threadIdx.x];
+    gl[threadIdx.x] = rbf(total);
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float v[IXT_MOE_MAX_TOPK], ex[IXT_MOE_MAX_TOPK];
+  uint32_t taken = 0;
+  for (int j = 0; j < top_k; ++j) {
+    int best = -1;
+    for (int e = 0; e < NEXP; ++e)
+      if (!((taken >> e) & 1u) && (best < 0 || gl[e] > gl[best])) best = e;
+    taken |= 1u << best;
+    idx_out[(size_t)r * top_k + j] = best;
+    v[j] = gl[best];
+  }
+  float s = 0.0f;
+  for (int j = 0; j < top_k; ++j) { ex[j] = ixt_exp(v[j] - v[0]); s = s + ex[j]; }
+  for (int j = 0; j < top_k; ++j) w_out[(size_t)r * top_k + j] = rbf(ex[j] / s);
+}
+
 // Expert e's down-projection slices -> bf16 -> the (row, j) slots that selected e.  grid = ((E + 255) / 256, R), block 256.
 __global__ __launch_bounds__(256) void k_moe_scatter(const float* part, int slices, size_t slice_stride, int E, int e, int top_k, const int32_t* idx,
                                                      bf16_t* ybuf /*[R][top_k][E]*/) {

@@ -480,3 +480,323 @@ __global__ __launch_bounds__(NW * 64) void k_attn_small(DecAttnArgs a) {
 #undef IXT_VLOAD
 #undef IXT_VBATCH
 }
+
+// =====================================================================================================
+// Decode attention for VERY few rows: the keys of one (row, kv head) split over S blocks.  With R x nkv blocks far below the CU count a block of
+// k_attn_small reads its head's whole K and V through ONE CU (394 KB at 770 keys: 8-9 us at the 30-47 GB/s a CU draws from HBM); here S
+// blocks -- on S CUs of the same XCD: the grid is (nkv, R, S) and nkv is a multiple of 8, so the S blocks of a (row, kv head) differ by a
+// multiple of 8 in dispatch order -- take a contiguous run of super-blocks each.  The operation order is the contract's, unchanged:
+//   scores: one fma chain over d                                  (local)
+//   m = max over ALL keys                                         -> exchange 1: the blocks' maxima
+//   e = exp*(s - m); page sums in key order                       (local)
+//   l = page sums added in page order                             -> exchange 2: every block's page sums (each block adds ALL of them in order)
+//   p = bf16(e / l); PV: one fma chain over a page's tokens, the 4 pages of a super-block added in order   (local)
+//   out = super-block sums added in order                         -> exchange 3: the LAST block to arrive adds them (and re-arms the counters)
+// Exchanges go through a small global workspace per (row, kv head): agent-scope stores, a counter, agent-scope loads; the waits are bounded
+// (IXT_SPIN_LIMIT polls, then the error word is set and the block goes on -- wrong numbers, which the caller reports, but never a hang).  All
+// S blocks of a launch are resident at once (the host launches no more blocks than the occupancy query says fit the chip), so nobody waits for a
+// block that cannot start.
+// Wave w of a block owns page 4 sb + w of each of its super-blocks in both phases: scores with lane = key (P <= 64 lanes busy), PV with
+// lane = 2 or 4 features (HD / FPL <= 64 lanes busy), all of a page's loads in flight at once.  Soft cap and sliding window as in k_attn_pv.
+// grid = (nkv, R, S), block 256.  LDS = GQ HD + GQ Tmax' + mpg' + 32 + GQ 4 HD + GQ mpg' floats.
+// =====================================================================================================
+#define IXT_SPIN_LIMIT (1 << 18)
+struct SplitWs {
+  int32_t* cnt;     // [R][nkv][4] arrival counters (zero between launches)
+  float* ws;        // [R][nkv][stride]: maxima [GQ][16], page sums [GQ][mpgp], super-block sums [GQ][nsb_max][HD]
+  size_t stride;
+  int32_t* err;     // set to 1 when a wait gave up
+  int mpgp;
+  float cap;        // > 0: score = ixt_tanh(score / cap) * cap before the max (attn_logits_soft_cap, attentions.py:1257-1259), as k_attn_pv
+  int window;       // > 0: keys j <= pos - window are invisible (LOCAL_SLIDING, attentions.py:625-631): e_j = p_j = +0, every sum unchanged
+};
+
+// The exchanged words are written and read with agent-scope accesses (sc1: they bypass the XCD-private L2 state, so no cache write-back or
+// invalidate is needed -- measured: with __threadfence() / acquire fences around the counter a one-utterance step took 1.64 instead of 1.05 ms).
+__device__ __forceinline__ void ixt_xst(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ixt_xld(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// Eight agent-scope loads IN FLIGHT together (v[i] = p[i * stride], i < n <= 8; the rest 0).  The compiler waits for every relaxed atomic
+// load before it issues the next one (a 33-term sum took 33 memory round trips: Gemma-2 decode 4.5 -> 5.1 ms per step), so these are written
+// out: the loads, then ONE wait that owns all eight registers -- no use of a value can be scheduled in front of it.  n is wave-uniform.
+__device__ __forceinline__ void ixt_xld8(const float* p, size_t stride, int n, float (&v)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    v[i] = 0.0f;
+    if (i < n) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[i]) : "v"(p + (size_t)i * stride) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : : "memory");
+}
+__device__ __forceinline__ void ixt_xld16(const float* p, size_t stride, int n, float (&v)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = 0.0f;
+    if (i < n) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[i]) : "v"(p + (size_t)i * stride) : "memory");
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
+}
+__device__ __forceinline__ void ixt_arrive_and_wait(int32_t* cnt, int target, int32_t* err, int tid) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's exchange stores have completed (at agent scope: they are sc1 stores)
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int it = 0;
+    while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++it > IXT_SPIN_LIMIT) { __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
+  }
+  __syncthreads();
+}
+
+template <int HD, int GQ>
+__global__ __launch_bounds__(256) void k_attn_split(DecAttnArgs a, SplitWs w) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  static_assert(HD <= 256 && HD % 16 == 0, "one wave covers a page's features, FPL per lane");
+  constexpr int FPL = HD >= 128 ? HD / 64 : 2;      // PV: features per lane (2: one dword per token, 4: two)
+  constexpr int VW = FPL / 2;
+  const AttnGeom& g = a.g;
+  const int kvh = blockIdx.x, r = blockIdx.y, s = blockIdx.z, S = gridDim.z;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n_out = g.nq * HD;
+  if (!a.row_active[r]) {
+    if (s == 0) for (int i = tid; i < GQ * HD; i += 256) a.out[xidx(r, kvh * GQ * HD + i, n_out)] = 0;
+    return;
+  }
+  const int tp = (g.Tmax + 3) & ~3;
+  float* qs = sm;                                   // [GQ][HD]
+  float* ebuf = qs + GQ * HD;                       // [GQ][Tmax'] scores -> exps -> P of the LOCAL keys (index: local page * P + token)
+  int32_t* pm = reinterpret_cast<int32_t*>(ebuf + (size_t)GQ * tp);   // [mpg'] local page list
+  float* wred = reinterpret_cast<float*>(pm + w.mpgp);                // [16] wave maxima, [16..16+GQ) m, [24..24+GQ) l
+  float* pacc = wred + 32;                          // [GQ][4][HD] page chains of the current super-block
+  float* lps = pacc + (size_t)GQ * 4 * HD;          // [GQ][mpg'] every block's page sums
+  const int pos = a.row_pos[r];
+  const int kv_len = pos + 1;
+  const int pages = (kv_len + g.P - 1) / g.P;
+  const int nsb = (pages + IXT_SB - 1) / IXT_SB;
+  const int sb0 = (int)((long)nsb * s / S), sb1 = (int)((long)nsb * (s + 1) / S);
+  const int p0 = sb0 * IXT_SB, p1 = min(pages, sb1 * IXT_SB);
+  const int npl = max(p1 - p0, 0);                  // local pages
+  const int nkl = npl > 0 ? min(kv_len, p1 * g.P) - p0 * g.P : 0;   // local keys
+  const int jvis = ((w.window > 0 && kv_len > w.window) ? kv_len - w.window : 0) - p0 * g.P;   // first visible key, as a local index
+  const size_t pair = (size_t)r * g.nkv + kvh;
+  int32_t* cnt = w.cnt + pair * 4;
+  float* gmx = w.ws + pair * w.stride;              // [GQ][16]
+  float* gps = gmx + GQ * 16;                        // [GQ][mpgp]
+  float* gsb = gps + (size_t)GQ * w.mpgp;           // [GQ][nsb_max][HD]
+  {
+    const int32_t* prow = a.page_map + (size_t)a.row_slot[r] * g.mpg + p0;
+    for (int i = tid; i < npl; i += 256) pm[i] = prow[i];
+    const bf16_t* qsrc = a.qbuf + ((size_t)r * g.nq + kvh * GQ) * HD;
+    for (int i = tid; i < GQ * HD; i += 256) qs[i] = bf2f(qsrc[i]);
+  }
+  __syncthreads();
+
+  // ---- scores of the local keys: wave = page of the super-block, lane = key.  A page's key goes through the registers in two halves of d
+  //      (half f = 2 i + h of the wave's i-th page); four half buffers in flight up to head_dim 128, two at 256 (with four, the 256 registers
+  //      they take leave nothing else in the file: the loads were waited for one by one, 87 us per launch at 4100 keys).
+  constexpr int KH = HD / 16;             // 16-byte d-chunks per half
+  {
+    const int nloc = sb1 - sb0;           // the wave's pages: one per local super-block
+    float acc[GQ];
+#define IXT_SKLOAD(DST_, F_)                                                                                      \
+    do {                                                                                                          \
+      const int i_ = (F_) >> 1, h_ = (F_) & 1, p_ = (sb0 + i_) * IXT_SB + wave;                                   \
+      if (i_ < nloc && p_ < pages && lane < g.P && p_ * g.P + lane < kv_len) {                                    \
+        const bf16_t* kp_ = a.kpages + kpage_off(g, pm[p_ - p0], kvh, h_ * KH, lane);                             \
+        _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) DST_[dc] = *reinterpret_cast<const u32x4*>(kp_ + (size_t)dc * g.P * 8); \
+      }                                                                                                           \
+    } while (0)
+#define IXT_SKHALF(BUF_, F_)                                                                                      \
+    do {                                                                                                          \
+      const int i_ = (F_) >> 1, h_ = (F_) & 1, p_ = (sb0 + i_) * IXT_SB + wave;                                   \
+      if (h_ == 0) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = 0.0f; }                              \
+      if (i_ < nloc && p_ < pages && lane < g.P && p_ * g.P + lane < kv_len) {                                    \
+        _Pragma("unroll") for (int dc = 0; dc < KH; ++dc) {                                                       \
+          const float kf[8] = {bflo(BUF_[dc].x), bfhi(BUF_[dc].x), bflo(BUF_[dc].y), bfhi(BUF_[dc].y),            \
+                               bflo(BUF_[dc].z), bfhi(BUF_[dc].z), bflo(BUF_[dc].w), bfhi(BUF_[dc].w)};           \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                        \
+            const float4 qa = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8);                 \
+            const float4 qb = *reinterpret_cast<const float4*>(qs + q * HD + (h_ * KH + dc) * 8 + 4);             \
+            float sacc = acc[q];                                                                                  \
+            sacc = __builtin_fmaf(qa.x, kf[0], sacc); sacc = __builtin_fmaf(qa.y, kf[1], sacc);                   \
+            sacc = __builtin_fmaf(qa.z, kf[2], sacc); sacc = __builtin_fmaf(qa.w, kf[3], sacc);                   \
+            sacc = __builtin_fmaf(qb.x, kf[4], sacc); sacc = __builtin_fmaf(qb.y, kf[5], sacc);                   \
+            sacc = __builtin_fmaf(qb.z, kf[6], sacc); sacc = __builtin_fmaf(qb.w, kf[7], sacc);                   \
+            acc[q] = sacc;                                                                                        \
+          }                                                                                                       \
+        }                                                                                                         \
+        if (h_ == 1) {                                                                                            \
+          if (w.cap > 0.0f) { _Pragma("unroll") for (int q = 0; q < GQ; ++q) acc[q] = ixt_tanh(acc[q] / w.cap) * w.cap; } \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) ebuf[(size_t)q * tp + (p_ - p0) * g.P + lane] = acc[q];  \
+        }                                                                                                         \
+      }                                                                                                           \
+    } while (0)
+    if constexpr (HD <= 128) {
+      u32x4 k0[KH], k1[KH], k2[KH], k3[KH];
+      IXT_SKLOAD(k0, 0); IXT_SKLOAD(k1, 1); IXT_SKLOAD(k2, 2); IXT_SKLOAD(k3, 3);
+      for (int f = 0; f < 2 * nloc; f += 4) {
+        IXT_SKHALF(k0, f);
+        IXT_SKHALF(k1, f + 1);
+        IXT_SKLOAD(k0, f + 4); IXT_SKLOAD(k1, f + 5);
+        if (f + 2 < 2 * nloc) {
+          IXT_SKHALF(k2, f + 2);
+          IXT_SKHALF(k3, f + 3);
+          IXT_SKLOAD(k2, f + 6); IXT_SKLOAD(k3, f + 7);
+        }
+      }
+    } else {
+      u32x4 k0[KH], k1[KH];
+      IXT_SKLOAD(k0, 0); IXT_SKLOAD(k1, 1);
+      for (int f = 0; f < 2 * nloc; f += 2) {
+        IXT_SKHALF(k0, f);
+        IXT_SKLOAD(k0, f + 2);
+        IXT_SKHALF(k1, f + 1);
+        IXT_SKLOAD(k1, f + 3);
+      }
+    }
+#undef IXT_SKLOAD
+#undef IXT_SKHALF
+  }
+  // the first super-block's values: in flight across both exchanges.  lane = feature pair, one 4-byte load per token
+  constexpr int VT = 32;                             // tokens of a page in flight at once
+  const bool dl = lane < HD / FPL;
+  uint32_t va[VT][VW], vb[VT][VW];
+#define IXT_SVLOAD(DST_, SB_, T0_)                                                                                \
+  do {                                                                                                            \
+    const int p_ = (SB_) * IXT_SB + wave;                                                                         \
+    if ((SB_) < sb1 && p_ < pages && dl) {                                                                        \
+      const int nt_ = min(g.P, kv_len - p_ * g.P) - (T0_);                                                        \
+      const bf16_t* vp_ = a.vpages + vpage_off(g, pm[p_ - p0], kvh, (T0_)) + FPL * lane;                          \
+      _Pragma("unroll") for (int u = 0; u < VT; ++u) {                                                            \
+        if (u < nt_) {                                                                                            \
+          if constexpr (VW == 1) DST_[u][0] = *reinterpret_cast<const uint32_t*>(vp_ + (size_t)u * HD);           \
+          else { const uint2 t2_ = *reinterpret_cast<const uint2*>(vp_ + (size_t)u * HD); DST_[u][0] = t2_.x; DST_[u][1] = t2_.y; } \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  IXT_SVLOAD(va, sb0, 0);
+  IXT_SVLOAD(vb, sb0 + 1, 0);
+  __syncthreads();
+  // ---- exchange 1: maxima
+  for (int q = 0; q < GQ; ++q) {
+    float m = -INFINITY;
+    const float* e = ebuf + (size_t)q * tp;
+    for (int j = tid; j < nkl; j += 256) { if (j >= jvis) m = fmaxf(m, e[j]); }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if (lane == 0) wred[q * 4 + wave] = m;
+  }
+  __syncthreads();
+  if (tid < GQ) ixt_xst(gmx + tid * 16 + s, fmaxf(fmaxf(wred[tid * 4], wred[tid * 4 + 1]), fmaxf(wred[tid * 4 + 2], wred[tid * 4 + 3])));
+  ixt_arrive_and_wait(cnt, S, w.err, tid);
+  if (tid < GQ) {
+    float mv[16];
+    ixt_xld16(gmx + tid * 16, 1, S, mv);
+    float m = mv[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i) if (i < S) m = fmaxf(m, mv[i]);
+    wred[16 + tid] = m;
+  }
+  __syncthreads();
+  // ---- exps, page sums; exchange 2
+  for (int q = 0; q < GQ; ++q) {
+    float* e = ebuf + (size_t)q * tp;
+    const float m = wred[16 + q];
+    for (int j = tid; j < nkl; j += 256) e[j] = j >= jvis ? ixt_exp(e[j] - m) : 0.0f;
+  }
+  __syncthreads();
+  for (int i = tid; i < GQ * npl; i += 256) {
+    const int q = i / npl, pl = i % npl;
+    const float* ep = ebuf + (size_t)q * tp + (size_t)pl * g.P;
+    const int n = min(g.P, kv_len - (p0 + pl) * g.P);
+    float sacc = 0.0f;
+    for (int t = 0; t < n; ++t) sacc = sacc + ep[t];
+    ixt_xst(gps + (size_t)q * w.mpgp + p0 + pl, sacc);
+  }
+  ixt_arrive_and_wait(cnt + 1, S, w.err, tid);
+  for (int i = tid; i < GQ * pages; i += 256) lps[(i / pages) * w.mpgp + i % pages] = ixt_xld(gps + (size_t)(i / pages) * w.mpgp + i % pages);   // one load per thread, all in flight
+  __syncthreads();
+  if (tid < GQ) {
+    float l = 0.0f;
+    for (int p = 0; p < pages; ++p) l = l + lps[tid * w.mpgp + p];
+    wred[24 + tid] = l;
+  }
+  __syncthreads();
+  for (int q = 0; q < GQ; ++q) {
+    float* e = ebuf + (size_t)q * tp;
+    const float l = wred[24 + q];
+    for (int j = tid; j < nkl; j += 256) e[j] = rbf(e[j] / l);
+  }
+  __syncthreads();
+  // ---- PV: wave = page, lane = feature pair; the super-block's four page chains added in page order
+#define IXT_SVDOT(BUF_, SB_, T0_)                                                                                 \
+  do {                                                                                                            \
+    const int p_ = (SB_) * IXT_SB + wave;                                                                         \
+    if (p_ < pages && dl) {                                                                                       \
+      const int nt_ = min(g.P, kv_len - p_ * g.P) - (T0_);                                                        \
+      _Pragma("unroll") for (int u = 0; u < VT; ++u) {                                                            \
+        if (u < nt_) {                                                                                            \
+          _Pragma("unroll") for (int q = 0; q < GQ; ++q) {                                                        \
+            const float pv_ = ebuf[(size_t)q * tp + (size_t)(p_ - p0) * g.P + (T0_) + u];                         \
+            _Pragma("unroll") for (int x = 0; x < VW; ++x) {                                                      \
+              acc[q][2 * x] = __builtin_fmaf(pv_, bflo(BUF_[u][x]), acc[q][2 * x]);                               \
+              acc[q][2 * x + 1] = __builtin_fmaf(pv_, bfhi(BUF_[u][x]), acc[q][2 * x + 1]);                       \
+            }                                                                                                     \
+          }                                                                                                       \
+        }                                                                                                         \
+      }                                                                                                           \
+    }                                                                                                             \
+  } while (0)
+  for (int sb = sb0; sb < sb1; ++sb) {       // pages of at most VT tokens (the host's condition); va / vb alternate, two super-blocks ahead
+    float acc[GQ][FPL];
+#pragma unroll
+    for (int q = 0; q < GQ; ++q)
+#pragma unroll
+      for (int x = 0; x < FPL; ++x) acc[q][x] = 0.0f;
+    if (((sb - sb0) & 1) == 0) {
+      IXT_SVDOT(va, sb, 0);
+      IXT_SVLOAD(va, sb + 2, 0);
+    } else {
+      IXT_SVDOT(vb, sb, 0);
+      IXT_SVLOAD(vb, sb + 2, 0);
+    }
+    if (dl) {
+#pragma unroll
+      for (int q = 0; q < GQ; ++q)
+#pragma unroll
+        for (int x = 0; x < FPL; x += 2) *reinterpret_cast<float2*>(pacc + ((size_t)q * 4 + wave) * HD + FPL * lane + x) = make_float2(acc[q][x], acc[q][x + 1]);
+    }
+    __syncthreads();
+    for (int i = tid; i < GQ * HD; i += 256) {
+      const int q = i / HD, d = i % HD;
+      float ss = 0.0f;
+#pragma unroll
+      for (int pg = 0; pg < IXT_SB; ++pg) ss = ss + pacc[((size_t)q * 4 + pg) * HD + d];
+      ixt_xst(gsb + ((size_t)q * g.nsb_max + sb) * HD + d, ss);
+    }
+    __syncthreads();
+  }
+#undef IXT_SVLOAD
+#undef IXT_SVDOT
+  // ---- exchange 3: the last block to arrive adds the super-block sums in order
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) wred[0] = (float)__hip_atomic_fetch_add(cnt + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if ((int)wred[0] != S - 1) return;
+  for (int i = tid; i < GQ * HD; i += 256) {
+    const int q = i / HD, d = i % HD;
+    float t = 0.0f;
+    for (int sb = 0; sb < nsb; sb += 16) {
+      float sv[16];
+      ixt_xld16(gsb + ((size_t)q * g.nsb_max + sb) * HD + d, HD, min(16, nsb - sb), sv);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) if (sb + k < nsb) t = t + sv[k];
+    }
+    a.out[xidx(r, (kvh * GQ + q) * HD + d, n_out)] = f2bf(t);
+  }
+  if (tid < 3) __hip_atomic_store(cnt + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}

@@ -175,6 +175,13 @@ class MaxEngine(engine_api.Engine):
     _lib.check(self.lib.ixt_pages_status(self._ctx, out, 0, ctypes.c_void_p(_stream_ptr())))
     self._raise_if_new_failure(out[0], out[1], what)
 
+  def exchange_status(self, reset: bool = True) -> int:
+    """1 if a bounded wait of the split decode attention (few rows: the blocks of one head exchange their softmax statistics inside a launch)
+    ever gave up since the last reset -- the numbers of that step are wrong --, else 0.  Synchronises the stream."""
+    out = (ctypes.c_int32 * 1)()
+    _lib.check(self.lib.ixt_exchange_status(self._ctx, out, 1 if reset else 0, ctypes.c_void_p(_stream_ptr())))
+    return int(out[0])
+
   def close(self) -> None:
     """Give the engine's HBM (weights copy, page pools, workspaces) back now; the engine cannot be used afterwards.  Handles returned by
     earlier calls keep a reference to the engine object, so waiting for the garbage collector can hold 100+ GB for a long time."""

@@ -90,6 +90,7 @@ def _run_pair(cfg, eng, params, orc, prompts, steps, check_logits, chunks):
     kg, vg = eng.gather_kv(H.sublayers(cfg) - 1, slot, n)
     ko, vo = orc.model.gather_kv(H.sublayers(cfg) - 1, orc.page_state.page_map[slot], n)
     assert np.array_equal(H.bits(kg), ko) and np.array_equal(H.bits(vg), vo)
+  assert eng.exchange_status() == 0      # no bounded wait of the split decode attention gave up
   del eng
   torch.cuda.synchronize()
   return np.stack(out, 0)
@@ -179,6 +180,22 @@ def test_head_dim_128_mha_page32(fused):
   p0 = H.synth.synth_prompt(cfg.vocab_size, 64, 1)
   p1 = H.synth.synth_prompt(cfg.vocab_size, 64, 2)
   run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"attn_fused_min_blocks": 1, "attn_wave_pairs": fused - 1} if fused else None)
+
+
+@pytest.mark.parametrize("split", [0, 102, 103, 108])   # 100 + S: S blocks even where the one-block form would be taken
+@pytest.mark.parametrize("geom", ["mha128", "gqa2_64", "gqa4_128"])
+def test_split_decode_attention(split, geom):
+  """Few decode rows: the keys of a (row, kv head) over `split` blocks of one launch that exchange maxima, page sums and super-block sums through
+  HBM (k_attn_split; 0: k_attn_small, one block per pair).  200 steps from 64- and 33-token prompts with 32-token pages: 3 to 9 pages = 1 to 3
+  super-blocks, so blocks without keys, blocks with a partial last page and page-boundary crossings all occur; bit-exact against the oracle."""
+  heads = {"mha128": (2, 2, 128), "gqa2_64": (4, 2, 64), "gqa4_128": (8, 2, 128)}[geom]
+  cfg = H.make_config(base_emb_dim=256, base_num_query_heads=heads[0], base_num_kv_heads=heads[1], head_dim=heads[2], base_mlp_dim=384,
+                      base_num_decoder_layers=2, vocab_size=2048, model_name="default", per_device_batch_size=2.0,
+                      max_prefill_predict_length=64, max_target_length=320, pagedattn_tokens_per_page=32, pagedattn_num_pages=24)
+  w = H.synth.synth_weights(cfg, 4)
+  p0 = H.synth.synth_prompt(cfg.vocab_size, 64, 1)
+  p1 = H.synth.synth_prompt(cfg.vocab_size, 64, 2)
+  run_pair(cfg, w, [p0, (p1[0], 33)], steps=200, check_logits=False, options={"small_attn_split": split})
 
 
 @pytest.mark.parametrize("hd", [64, 128])
