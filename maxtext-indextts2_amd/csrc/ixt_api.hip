@@ -112,6 +112,7 @@ struct ixt_ctx {
   // few rows: the keys of a (row, kv head) split over `S` blocks of k_attn_split (S = min(small_attn_split, 256 / (rows * kv heads)); < 2: k_attn_small)
   int small_attn_split = 16;
   int split_capacity = -1;   // blocks of k_attn_split the chip holds at once (occupancy query, once)
+  int gemma_tile = 1;        // Gemma blocks: tiled prefill attention (0: the per-row scores / PV / combine kernels)
   int moe_route_blocks = 1;  // router: one wave per 512-k block, all experts at once (0: one wave per expert)
   int32_t* split_cnt = nullptr;   // [16][KV][4] arrival counters (zero between launches) + the error word behind them
   float* split_ws = nullptr;      // [16][KV][split_stride]
@@ -1261,7 +1262,7 @@ static void launch_decode_attn(ixt_ctx* c, int layer, int R, const DotResult& dr
 // prefill rows (q in qbuf, K/V already in the pages): NQ query vectors per block share every K / V load.  false: the score rows of
 // len_hint keys do not fit the LDS (the caller takes the per-row kernels).
 template <int HD, int GQ, int NQ>
-static int tile_attn_t(ixt_ctx* c, int layer, int R, int lmax, size_t lds, hipStream_t st) {
+static int tile_attn_t(ixt_ctx* c, int layer, int R, int lmax, size_t lds, hipStream_t st, float cap, int window) {
   static bool attr_done = false;
   if (!attr_done) {   // up to 160 KiB of dynamic LDS: the attribute once per kernel
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_attn_tile<HD, GQ, NQ>), hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
@@ -1269,7 +1270,7 @@ static int tile_attn_t(ixt_ctx* c, int layer, int R, int lmax, size_t lds, hipSt
   }
   TileAttnArgs ta;
   ta.row_slot = c->row_slot; ta.row_pos = c->row_pos; ta.row_active = c->row_active; ta.page_map = c->ps.page_map;
-  ta.qbuf = c->qbuf; ta.kpages = c->kpages_l[layer]; ta.vpages = c->vpages_l[layer]; ta.out = c->ao; ta.g = c->geom; ta.R = R; ta.lmax = lmax;
+  ta.qbuf = c->qbuf; ta.kpages = c->kpages_l[layer]; ta.vpages = c->vpages_l[layer]; ta.out = c->ao; ta.g = c->geom; ta.R = R; ta.lmax = lmax; ta.cap = cap; ta.window = window;
   constexpr int TQ = NQ / GQ;
   hipLaunchKernelGGL((k_attn_tile<HD, GQ, NQ>), dim3(c->geom.nkv, (R + TQ - 1) / TQ), dim3(256), lds, st, ta);
   LAUNCHCHK();
@@ -1284,13 +1285,13 @@ static bool tile_attn_fits(const ixt_ctx* c, int R, int len_hint, bool decode) {
   const int lmax = (std::min(len_hint, c->Tmax) + 3) & ~3;
   return tile_attn_lds(c, 8, lmax) <= 150 * 1024;
 }
-static int launch_attention_tile(ixt_ctx* c, int layer, int R, int len_hint, hipStream_t st) {
+static int launch_attention_tile(ixt_ctx* c, int layer, int R, int len_hint, hipStream_t st, float cap = 0.0f, int window = 0) {
   const int lmax = (std::min(len_hint, c->Tmax) + 3) & ~3;
-  const bool wide = tile_attn_lds(c, 16, lmax) <= 150 * 1024;
+  const bool wide = tile_attn_lds(c, 16, lmax) <= 150 * 1024 && c->D <= 128;   // (head_dim 256 with 16 vectors: 100+ bytes of scratch per lane)
   const size_t lds = tile_attn_lds(c, wide ? 16 : 8, lmax);
 #define ATT(HD_, GQ_)                                                                             \
-  if (c->D == HD_ && c->GQ == GQ_) return wide ? tile_attn_t<HD_, GQ_, 16>(c, layer, R, lmax, lds, st) : tile_attn_t<HD_, GQ_, 8>(c, layer, R, lmax, lds, st);
-  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4)
+  if (c->D == HD_ && c->GQ == GQ_) return wide ? tile_attn_t<HD_, GQ_, 16>(c, layer, R, lmax, lds, st, cap, window) : tile_attn_t<HD_, GQ_, 8>(c, layer, R, lmax, lds, st, cap, window);
+  ATT(128, 1) ATT(128, 2) ATT(128, 4) ATT(64, 1) ATT(64, 2) ATT(64, 4) ATT(256, 1) ATT(256, 2) ATT(256, 4)
 #undef ATT
   return set_err(IXT_ERR_UNSUPPORTED, "tiled attention: head_dim %d with %d query heads per kv head", c->D, c->GQ);
 }
@@ -1508,6 +1509,7 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
   bf16_t* hnext = c->h_b;
   const bool all_rows = nl == R && lrow0 == 0 && lrows == nullptr;
   const size_t glds = sizeof(float) * ((size_t)E + 128);
+  const bool attn_tiled = c->gemma_tile && tile_attn_fits(c, R, len_hint, false) && attn_split_factor(c, R) <= 1;
   TRY(launch_rownorm(c, 0, R, tokens, nullptr, nullptr, hcur, c->layers[0].ln1, c->xn, st));
   for (int l = 0; l < c->L; ++l) {
     const LayerW& w = c->layers[l];
@@ -1528,6 +1530,8 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
     const int attn_split = attn_split_factor(c, R);   // few rows (decode): the keys of a head over several blocks of ONE launch instead of scores / PV / combine
     if (attn_split > 1) {
       TRY(launch_attn_split(c, l, R, attn_split, st, cf.attn_logits_soft_cap, local ? cf.sliding_window_size : 0));
+    } else if (attn_tiled) {   // prefill rows: consecutive rows share their page group's K and V loads (k_attn_tile with the cap and the window)
+      TRY(launch_attention_tile(c, l, R, len_hint, st, cf.attn_logits_soft_cap, local ? cf.sliding_window_size : 0));
     } else {
       c->pv_cap = cf.attn_logits_soft_cap;
       c->pv_window = local ? cf.sliding_window_size : 0;
@@ -2240,7 +2244,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0}, {"small_attn_split", &c->small_attn_split, 0}, {"moe_route_blocks", &c->moe_route_blocks, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0}, {"small_attn_split", &c->small_attn_split, 0}, {"moe_route_blocks", &c->moe_route_blocks, 0}, {"gemma_tile", &c->gemma_tile, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

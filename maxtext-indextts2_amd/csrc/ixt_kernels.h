@@ -1670,6 +1670,8 @@ struct TileAttnArgs {
   AttnGeom g;
   int R;
   int lmax;                           // keys one score row holds (multiple of 4); a group reaching further is left to the caller's guard
+  float cap;                          // > 0: score = ixt_tanh(score / cap) * cap before the max (attn_logits_soft_cap, attentions.py:1257-1259), as k_attn_pv
+  int window;                         // > 0: keys j <= pos - window are invisible (LOCAL_SLIDING, attentions.py:625-631): e_j = p_j = +0, every sum unchanged
 };
 typedef uint32_t ixt_u32x16 __attribute__((ext_vector_type(16)));
 typedef float ixt_f32x2 __attribute__((ext_vector_type(2)));
@@ -1684,7 +1686,9 @@ __global__ __launch_bounds__(256, 2) void k_attn_tile(TileAttnArgs a) {
   constexpr int SBB = PPB / IXT_SB;       // super-blocks of a pass
   constexpr int NQH = NQ / 2;             // the page chains go through LDS in two halves of the query vectors
   constexpr int NT = NQH * HD / 256;      // (query vector, d) totals per thread and half
-  constexpr int NP = HD / 32;             // a query vector = NP scalar loads of 16 dwords
+  constexpr int NH = HD > 128 ? 2 : 1;    // head_dim 256: the key goes through the registers in two halves of d, the chain's partial sum waits in the score row
+  constexpr int HDH = HD / NH;
+  constexpr int NP = HDH / 32;            // a query vector's half = NP scalar loads of 16 dwords
   constexpr int QW = NQ / 4;              // query vectors per wave in the softmax phase
   static_assert(NQ % GQ == 0 && NQ % 8 == 0 && TQ <= 32 && (NQH * HD) % 256 == 0 && PPB % IXT_SB == 0, "tile geometry");
   extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1740,45 +1744,54 @@ __global__ __launch_bounds__(256, 2) void k_attn_tile(TileAttnArgs a) {
     const int ntile = (kv_all + 63) >> 6;
     for (int t = wave; t < ntile; t += 4) {
       const int j = t * 64 + lane;
-      ixt_f32x2 kf[HD / 2];                              // (k[2c], k[2c+1]): one packed fma takes either half for both of its lanes (op_sel)
-      if (j < kv_all) {
-        const bf16_t* kp = a.kpages + kpage_off(g, prow[j / g.P], kvh, 0, j % g.P);
-#pragma unroll
-        for (int c = 0; c < HD / 8; ++c) {
-          const u32x4 kr = *reinterpret_cast<const u32x4*>(kp + (size_t)c * g.P * 8);
-          kf[c * 4 + 0] = (ixt_f32x2){bflo(kr.x), bfhi(kr.x)}; kf[c * 4 + 1] = (ixt_f32x2){bflo(kr.y), bfhi(kr.y)};
-          kf[c * 4 + 2] = (ixt_f32x2){bflo(kr.z), bfhi(kr.z)}; kf[c * 4 + 3] = (ixt_f32x2){bflo(kr.w), bfhi(kr.w)};
-        }
-      } else {
-#pragma unroll
-        for (int c = 0; c < HD / 2; ++c) kf[c] = (ixt_f32x2){0.0f, 0.0f};
-      }
-      // query vectors (qv, qv + 1); rows past the end of the call read the last row (their scores are never stored)
 #define IXT_QPTR(QV_) ((ixt_cq16p)(a.qbuf + ((size_t)min(r0 + (QV_) / GQ, a.R - 1) * g.nq + kvh * GQ + (QV_) % GQ) * HD))
-      ixt_u32x16 ca = IXT_QPTR(0)[0], cb = IXT_QPTR(1)[0];
-      for (int qv = 0; qv < NQ; qv += 2) {
-        ixt_f32x2 acc = {0.0f, 0.0f};
 #pragma unroll
-        for (int part = 0; part < NP; ++part) {
-          ixt_u32x16 na, nb;                                   // the next 32 d of both vectors (the next pair's first 32 after the last part)
-          if (part + 1 < NP) { na = IXT_QPTR(qv)[part + 1]; nb = IXT_QPTR(qv + 1)[part + 1]; }
-          else { const int nq_ = qv + 2 < NQ ? qv + 2 : 0; na = IXT_QPTR(nq_)[0]; nb = IXT_QPTR(nq_ + 1)[0]; }
-          __builtin_amdgcn_sched_barrier(0);                   // the loads are issued here, ahead of the 32 fmas that hide them
+      for (int hh = 0; hh < NH; ++hh) {
+        ixt_f32x2 kf[HDH / 2];                           // (k[2c], k[2c+1]): one packed fma takes either half for both of its lanes (op_sel)
+        if (j < kv_all) {
+          const bf16_t* kp = a.kpages + kpage_off(g, prow[j / g.P], kvh, hh * (HDH / 8), j % g.P);
 #pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            // acc.x += qa[d] k[d], acc.y += qb[d] k[d] for d = 2k (first) and 2k + 1 (second): the key operand is one half of the
-            // register pair for both lanes of the packed fma -- the compiler would copy it into a second register instead
-            const ixt_f32x2 qlo = {bflo(ca[k]), bflo(cb[k])}, qhi = {bfhi(ca[k]), bfhi(cb[k])};
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(qlo), "v"(kf[part * 16 + k]));
-            asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(qhi), "v"(kf[part * 16 + k]));
+          for (int c = 0; c < HDH / 8; ++c) {
+            const u32x4 kr = *reinterpret_cast<const u32x4*>(kp + (size_t)c * g.P * 8);
+            kf[c * 4 + 0] = (ixt_f32x2){bflo(kr.x), bfhi(kr.x)}; kf[c * 4 + 1] = (ixt_f32x2){bflo(kr.y), bfhi(kr.y)};
+            kf[c * 4 + 2] = (ixt_f32x2){bflo(kr.z), bfhi(kr.z)}; kf[c * 4 + 3] = (ixt_f32x2){bflo(kr.w), bfhi(kr.w)};
           }
-          ca = na; cb = nb;
+        } else {
+#pragma unroll
+          for (int c = 0; c < HDH / 2; ++c) kf[c] = (ixt_f32x2){0.0f, 0.0f};
         }
-        const int i0 = qv / GQ, i1 = (qv + 1) / GQ;
-        const int p0 = ((grp >> i0) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i0]) : -1;
-        const int p1 = ((grp >> i1) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i1]) : -1;
-        if (j <= p0) ebuf[(size_t)qv * tp + j] = acc.x;
-        if (j <= p1) ebuf[(size_t)(qv + 1) * tp + j] = acc.y;
+        // query vectors (qv, qv + 1); rows past the end of the call read the last row (their scores are never stored)
+        ixt_u32x16 ca = IXT_QPTR(0)[hh * NP], cb = IXT_QPTR(1)[hh * NP];
+        for (int qv = 0; qv < NQ; qv += 2) {
+          ixt_f32x2 acc = {0.0f, 0.0f};
+          if (hh > 0 && j < kv_all) acc = (ixt_f32x2){ebuf[(size_t)qv * tp + j], ebuf[(size_t)(qv + 1) * tp + j]};   // the chain goes on where the first half of d left it
+#pragma unroll
+          for (int part = 0; part < NP; ++part) {
+            ixt_u32x16 na, nb;                                   // the next 32 d of both vectors (the next pair's first 32 of this half after the last part)
+            if (part + 1 < NP) { na = IXT_QPTR(qv)[hh * NP + part + 1]; nb = IXT_QPTR(qv + 1)[hh * NP + part + 1]; }
+            else { const int nq_ = qv + 2 < NQ ? qv + 2 : 0; na = IXT_QPTR(nq_)[hh * NP]; nb = IXT_QPTR(nq_ + 1)[hh * NP]; }
+            __builtin_amdgcn_sched_barrier(0);                   // the loads are issued here, ahead of the 32 fmas that hide them
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              // acc.x += qa[d] k[d], acc.y += qb[d] k[d] for d = 2k (first) and 2k + 1 (second): the key operand is one half of the
+              // register pair for both lanes of the packed fma -- the compiler would copy it into a second register instead
+              const ixt_f32x2 qlo = {bflo(ca[k]), bflo(cb[k])}, qhi = {bfhi(ca[k]), bfhi(cb[k])};
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(qlo), "v"(kf[part * 16 + k]));
+              asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(qhi), "v"(kf[part * 16 + k]));
+            }
+            ca = na; cb = nb;
+          }
+          if (hh + 1 < NH) {
+            if (j < kv_all) { ebuf[(size_t)qv * tp + j] = acc.x; ebuf[(size_t)(qv + 1) * tp + j] = acc.y; }
+          } else {
+            if (a.cap > 0.0f) { acc.x = ixt_tanh(acc.x / a.cap) * a.cap; acc.y = ixt_tanh(acc.y / a.cap) * a.cap; }
+            const int i0 = qv / GQ, i1 = (qv + 1) / GQ;
+            const int p0 = ((grp >> i0) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i0]) : -1;
+            const int p1 = ((grp >> i1) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i1]) : -1;
+            if (j <= p0) ebuf[(size_t)qv * tp + j] = acc.x;
+            if (j <= p1) ebuf[(size_t)(qv + 1) * tp + j] = acc.y;
+          }
+        }
       }
 #undef IXT_QPTR
     }
@@ -1786,18 +1799,19 @@ __global__ __launch_bounds__(256, 2) void k_attn_tile(TileAttnArgs a) {
 
     // ---- softmax statistics: wave w owns query vectors w QW .. w QW + QW - 1 and walks them through the phases side by side
     {
-      int kvl[QW];
+      int kvl[QW], jv[QW];                                // keys the vector sees: [jv, kvl)
       float m[QW], l[QW];
 #pragma unroll
       for (int u = 0; u < QW; ++u) {
         const int i = (wave * QW + u) / GQ;
         kvl[u] = ((grp >> i) & 1u) ? __builtin_amdgcn_readfirstlane(s_pos[i]) + 1 : 0;
+        jv[u] = (a.window > 0 && kvl[u] > a.window) ? kvl[u] - a.window : 0;
         m[u] = -INFINITY;
       }
 #pragma unroll
       for (int u = 0; u < QW; ++u) {
         const float* e = ebuf + (size_t)(wave * QW + u) * tp;
-        for (int j = lane; j < kvl[u]; j += 64) m[u] = fmaxf(m[u], e[j]);
+        for (int j = lane; j < kvl[u]; j += 64) { if (j >= jv[u]) m[u] = fmaxf(m[u], e[j]); }
       }
 #pragma unroll
       for (int off = 1; off < 64; off <<= 1) {
@@ -1807,7 +1821,7 @@ __global__ __launch_bounds__(256, 2) void k_attn_tile(TileAttnArgs a) {
 #pragma unroll
       for (int u = 0; u < QW; ++u) {
         float* e = ebuf + (size_t)(wave * QW + u) * tp;
-        for (int j = lane; j < kvl[u]; j += 64) e[j] = ixt_exp(e[j] - m[u]);
+        for (int j = lane; j < kvl[u]; j += 64) e[j] = j >= jv[u] ? ixt_exp(e[j] - m[u]) : 0.0f;
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
       __builtin_amdgcn_wave_barrier();

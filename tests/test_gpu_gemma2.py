@@ -103,6 +103,16 @@ def test_gemma2_head_dim_256_tiny():
   run_pair(cfg, w, prompts, steps=30)
 
 
+@pytest.mark.parametrize("tile", [1, 0])
+def test_gemma2_head_dim_256_tiled_prefill(tile):
+  """Prefill rows through k_attn_tile at head_dim 256 (the key in two halves of d, the chain's partial sum parked in the score row), with the soft
+  cap and a sliding window (40) shorter than the 96- and 70-token prompts, against the oracle; tile = 0: the per-row scores / PV / combine kernels."""
+  cfg = _cfg(head_dim=256, max_prefill_predict_length=96, max_target_length=160, per_device_batch_size=2.0, pagedattn_num_pages=96, sliding_window_size=40)
+  w = H.synth.synth_weights(cfg, 12)
+  prompts = [(H.synth.synth_prompt(cfg.vocab_size, 96, 90 + s)[0], [96, 70][s]) for s in range(2)]
+  run_pair(cfg, w, prompts, steps=8, options={"gemma_tile": tile})
+
+
 def test_gemma2_2b_widths():
   """The widths of configs/models/gemma2-2b.yml (emb 2304, 8 x 256 query heads over 4 kv heads, mlp 9216, vocab 256128, tied head, caps 50 / 30)
   with 2 of its 13 merged layers: every projection shape, the 256 128-column unembedding of the transposed table and head_dim 256 at 2 query heads
