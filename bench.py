@@ -294,6 +294,8 @@ def run_rank(args):
   tokens_per_pass = B * (args.decode_steps + 1)
   value = tokens_per_pass * args.steps * world / elapsed
   _log(f"rank {rank}: timed region done: {elapsed / args.steps * 1e3:.1f} ms per pass")
+  if not stub and hasattr(eng, "exchange_status") and eng.exchange_status() != 0:
+    raise RuntimeError("a bounded wait inside the split decode attention gave up during the timed passes: the run's tokens are not to be trusted")
 
   out = {"metric": "audio-tokens/sec (prefill+decode) @ 1B IndexTTS2", "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

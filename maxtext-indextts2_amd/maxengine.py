@@ -174,6 +174,9 @@ class MaxEngine(engine_api.Engine):
     out = (ctypes.c_int32 * 4)()
     _lib.check(self.lib.ixt_pages_status(self._ctx, out, 0, ctypes.c_void_p(_stream_ptr())))
     self._raise_if_new_failure(out[0], out[1], what)
+    if self.exchange_status() != 0:     # the stream is synchronised here anyway: the cheapest place to notice a decode step that went wrong
+      raise _lib.IxtError(f"{what}: a wait inside the split decode attention gave up in an earlier generate step (ixt_exchange_status); "
+                          "the tokens of that step are not to be trusted")
 
   def exchange_status(self, reset: bool = True) -> int:
     """1 if a bounded wait of the split decode attention (few rows: the blocks of one head exchange their softmax statistics inside a launch)
