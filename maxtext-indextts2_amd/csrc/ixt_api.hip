@@ -112,6 +112,8 @@ struct ixt_ctx {
   // few rows: the keys of a (row, kv head) split over `S` blocks of k_attn_split (S = min(small_attn_split, 256 / (rows * kv heads)); < 2: k_attn_small)
   int small_attn_split = 16;
   int split_capacity = -1;   // blocks of k_attn_split the chip holds at once (occupancy query, once)
+  int moe_mid_pairs = 0;     // routed experts: up to this many (row, expert) copies per launch take 64-row whole-K dots instead of the ring GEMM.  Measured SLOWER at Mixtral-8x7B's 256-token prefill (512 copies): 74.7 against 30.2 ms -- 4 waves per block cannot hide both operands' latency at 64 rows: off
+  int moe_fused_gate = 1;    // routed experts at few copies: wi as whole-K blocks with the SwiGLU epilogue (0: split-K slices + k_swiglu_part)
   int gemma_tile = 1;        // Gemma blocks: tiled prefill attention (0: the per-row scores / PV / combine kernels)
   int moe_route_blocks = 1;  // router: one wave per 512-k block, all experts at once (0: one wave per expert)
   int32_t* split_cnt = nullptr;   // [16][KV][4] arrival counters (zero between launches) + the error word behind them
@@ -1587,7 +1589,9 @@ static int forward_rows_gemma2(ixt_ctx* c, int R, const int32_t* tokens, int len
 //   more                LDS-ring GEMMs over 128-row groups with the SwiGLU epilogue / one f32 slice
 static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, const int32_t* idx, int npairs, int top_k, hipStream_t st, DotResult* res) {
   const int E = c->E, F = c->F;
-  const int align = npairs <= 64 ? 16 : 128;
+  // copies per launch: few (decode) -> 16-row expert ranges, split-K / whole-K dots; a prompt's worth (up to moe_mid_pairs) -> 64-row ranges, four row
+  // blocks per weight fragment (whole-K dots, the gate as epilogue); more -> 128-row ranges for the ring GEMM
+  const int align = npairs <= 64 ? 16 : ((!c->fp8 && npairs <= c->moe_mid_pairs) ? 64 : 128);
   const int rows_g = (npairs + align - 1) / align * align + align * c->NEL;
   if (rows_g > c->moe_rows_cap) return set_err(IXT_ERR_INVALID, "moe: %d copies exceed the routed workspaces (%d rows)", npairs, c->moe_rows_cap);
   hipLaunchKernelGGL(k_moe_plan, dim3(1), dim3(1024), 0, st, idx, npairs, c->E0, c->NEL, align, rows_g / 16, c->moe_pos, c->moe_rbexp, c->moe_cnt);
@@ -1626,6 +1630,24 @@ static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, cons
     res->slices = ch; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
     return IXT_OK;
   }
+  if (align == 64) {
+    const int zblocks = rows_g / 64;
+    auto whole = [&](auto kern, const bf16_t* xin, const bf16_t* wbase, size_t wstride, int K, int N, float* out, double out_bytes) {
+      const int nwaves = N / 16;
+      const int ti = timing_begin(c, st, (double)K * N * 2.0 * c->NEL + (double)rows_g * K * 2.0 + out_bytes);
+      dim3 grid((((nwaves + 3) / 4 + 7) / 8) * 8 * zblocks, 1, 1);
+      hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)64 * 1024, st, reinterpret_cast<const u32x4*>(xin), reinterpret_cast<const u32x4*>(wbase), K, N, rows_g, out, nwaves, zblocks,
+                         c->moe_rbexp, wstride);
+      timing_end(c, st, ti);
+    };
+    if ((size_t)rows_g * E > c->part_floats) return set_err(IXT_ERR_INVALID, "moe: output workspace too small");
+    whole(k_dotb<4, false, true, 1>, c->moe_xg, w.ewi[0], wi_stride, E, 2 * F, reinterpret_cast<float*>(c->moe_hact), (double)rows_g * F * 2.0);
+    LAUNCHCHK();
+    whole(k_dotb<4, false, true, 0>, c->moe_hact, w.ewout[0], wo_stride, F, E, c->part, (double)rows_g * E * 4.0);
+    LAUNCHCHK();
+    res->slices = 1; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
+    return IXT_OK;
+  }
   if (align == 16) {
     const int zblocks = rows_g / 16;
     auto dotg = [&](const bf16_t* xin, const bf16_t* wbase, size_t wstride, int K, int N) -> int {
@@ -1639,10 +1661,21 @@ static int moe_experts_routed(ixt_ctx* c, const LayerW& w, const bf16_t* x, cons
       LAUNCHCHK();
       return chains;
     };
-    int ch = dotg(c->moe_xg, w.ewi[0], wi_stride, E, 2 * F);
-    if (ch < 0) return ch;
-    hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, rows_g), dim3(256), 0, st, c->part, ch, (size_t)rows_g * 2 * F, F, c->moe_hact, c->moe_rbexp);
-    LAUNCHCHK();
+    int ch;
+    if (c->moe_fused_gate) {   // whole-K blocks with the gate as their epilogue: no f32 slices of the 2 F columns leave the chip
+      const int nwaves = 2 * F / 16;
+      const int ti = timing_begin(c, st, (double)E * 2 * F * 2.0 * c->NEL + (double)rows_g * E * 2.0 + (double)rows_g * F * 2.0);
+      dim3 grid((((nwaves + 3) / 4 + 7) / 8) * 8 * zblocks, 1, 1);
+      hipLaunchKernelGGL((k_dotb<1, false, true, 1>), grid, dim3(256), (size_t)16 * 1024, st, reinterpret_cast<const u32x4*>(c->moe_xg), reinterpret_cast<const u32x4*>(w.ewi[0]), E, 2 * F,
+                         rows_g, reinterpret_cast<float*>(c->moe_hact), nwaves, zblocks, c->moe_rbexp, wi_stride);
+      timing_end(c, st, ti);
+      LAUNCHCHK();
+    } else {
+      ch = dotg(c->moe_xg, w.ewi[0], wi_stride, E, 2 * F);
+      if (ch < 0) return ch;
+      hipLaunchKernelGGL(k_swiglu_part, dim3((F + 2047) / 2048, rows_g), dim3(256), 0, st, c->part, ch, (size_t)rows_g * 2 * F, F, c->moe_hact, c->moe_rbexp);
+      LAUNCHCHK();
+    }
     ch = dotg(c->moe_hact, w.ewout[0], wo_stride, F, E);
     if (ch < 0) return ch;
     res->slices = ch; res->slice_stride = (size_t)rows_g * E; res->ntiles = E / 16;
@@ -2244,7 +2277,7 @@ extern "C" int ixt_set_option(ixt_ctx* c, const char* name, int value) {
       {"gemm_split_min_blocks", &c->gemm_split_min_blocks, 1}, {"gemm_min_blocks", &c->gemm_min_blocks, 1}, {"gemm_min_rows", &c->gemm_min_rows, 1},
       {"unembed_gemm", &c->unembed_gemm, 0}, {"attn_wave_pairs", &c->attn_wave_pairs, 0}, {"attn_tile", &c->attn_tile, 0}, {"attn_tile_min_rows", &c->attn_tile_min_rows, 1}, {"dot_stream_min_blocks", &c->dot_stream_min_blocks, 1},
       {"ring_min_rows", &c->ring_min_rows, 1}, {"ring_cfg", &c->ring_cfg, 0}, {"ring_split", &c->ring_split, 0}, {"ring_wlayout", &c->ring_wlayout, 0}, {"ring_down", &c->ring_down, -1}, {"unembed_tall", &c->unembed_tall, 0}, {"ring_two_per_cu", &c->ring_two_per_cu, 0},
-      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0}, {"small_attn_split", &c->small_attn_split, 0}, {"moe_route_blocks", &c->moe_route_blocks, 0}, {"gemma_tile", &c->gemma_tile, 0},
+      {"small_rows", &c->small_rows, 0}, {"small_tpb", &c->small_tpb, 0}, {"small_attn_waves", &c->small_attn_waves, 4}, {"small_attn_max_blocks", &c->small_attn_max_blocks, 0}, {"dot_small", &c->dot_small, 0}, {"small_norm", &c->small_norm, 0}, {"small_prefetch", &c->small_prefetch, 0}, {"small_prefetch_blocks", &c->small_prefetch_blocks, 1}, {"moe_grouped", &c->moe_grouped, 0}, {"small_attn_split", &c->small_attn_split, 0}, {"moe_route_blocks", &c->moe_route_blocks, 0}, {"gemma_tile", &c->gemma_tile, 0}, {"moe_fused_gate", &c->moe_fused_gate, 0}, {"moe_mid_pairs", &c->moe_mid_pairs, 0},
   };
   for (const Opt& o : opts) {
     if (strcmp(name, o.name) != 0) continue;

@@ -84,7 +84,10 @@ __host__ __device__ __forceinline__ int qk_col(int i, int half) {
 //   the L2-resident slab lands and is written to LDS while the weight fragments are still on their way from HBM.
 //   Routed experts (rb_exp != nullptr; NRB = 1): row block rb belongs to expert rb_exp[rb], whose kernels start wstride 16-byte units after
 //   wt; a row block of no expert (-1) leaves at once (k_moe_plan, ixt_moe_kernels.h).
-template <int NRB, bool SPLIT, bool NT>
+//   EPI = 1 (whole-K blocks only): the columns are interleaved (wi_0, wi_1) tiles (k_tile_w mode 2) and `out` is the bf16 activation buffer of the
+//   next dot: the odd wave of a pair hands its totals to the even one through LDS, which writes bf16(bf16(a * bf16(sigmoid a)) * b) in the x layout
+//   (linears.py:331-361) -- no f32 slice leaves the chip (routed experts at decode: 132 MB of slices per layer and the kernel that re-read them).
+template <int NRB, bool SPLIT, bool NT, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, const u32x4* __restrict__ wt, int K, int N, int R,
                                                  float* __restrict__ out, int nwaves, int zblocks, const int32_t* __restrict__ rb_exp = nullptr,
                                                  size_t wstride = 0) {
@@ -174,7 +177,33 @@ __global__ __launch_bounds__(256, 2) void k_dotb(const u32x4* __restrict__ xt, c
     }
   }
 #undef IXT_WLOAD
-  if (!SPLIT && tile_ok) {
+  if constexpr (!SPLIT && EPI == 1) {
+    static_assert(EPI == 0 || !SPLIT, "the gate needs the whole-K totals");
+    __syncthreads();                                   // every wave is done with the last slab
+    f32x4* ex = reinterpret_cast<f32x4*>(xs);          // [wave pair][NRB][64 lanes]
+    if (wave & 1) {
+#pragma unroll
+      for (int b = 0; b < NRB; ++b) ex[((wave >> 1) * NRB + b) * 64 + lane] = tot[b];
+    }
+    __syncthreads();
+    if (!(wave & 1) && tile_ok && tile + 1 < nwaves) {
+      bf16_t* act = reinterpret_cast<bf16_t*>(out);
+      const int F = N >> 1, f0 = (tile >> 1) * 16 + cq * 4;
+#pragma unroll
+      for (int b = 0; b < NRB; ++b) {
+        const int row = (rb0 + b) * 16 + r_in;
+        if (row < R) {
+          const f32x4 up = ex[((wave >> 1) * NRB + b) * 64 + lane];
+          bf16_t o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = ixt_swiglu(rbf(tot[b][j]), rbf(up[j]));
+          uint2 ov;
+          ov.x = pack2(o[0], o[1]); ov.y = pack2(o[2], o[3]);
+          *reinterpret_cast<uint2*>(act + xidx(row, f0, F)) = ov;
+        }
+      }
+    }
+  } else if (!SPLIT && tile_ok) {
 #pragma unroll
     for (int b = 0; b < NRB; ++b) {
       const int row = (rb0 + b) * 16 + r_in;
