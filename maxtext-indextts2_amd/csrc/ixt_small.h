@@ -535,6 +535,21 @@ __device__ __forceinline__ void ixt_xld16(const float* p, size_t stride, int n, 
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
 }
+// two such batches (two output elements of a thread) behind ONE wait
+__device__ __forceinline__ void ixt_xld16x2(const float* p0, const float* p1, size_t stride, int n, float (&v)[16], float (&u)[16]) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    v[i] = 0.0f; u[i] = 0.0f;
+    if (i < n) {
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[i]) : "v"(p0 + (size_t)i * stride) : "memory");
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(u[i]) : "v"(p1 + (size_t)i * stride) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+               "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
+  asm volatile("" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]),
+               "+v"(u[8]), "+v"(u[9]), "+v"(u[10]), "+v"(u[11]), "+v"(u[12]), "+v"(u[13]), "+v"(u[14]), "+v"(u[15]) : : "memory");   // (after the wait: volatile statements keep their order)
+}
 __device__ __forceinline__ void ixt_arrive_and_wait(int32_t* cnt, int target, int32_t* err, int tid) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this thread's exchange stores have completed (at agent scope: they are sc1 stores)
   __syncthreads();
@@ -787,16 +802,31 @@ __global__ __launch_bounds__(256) void k_attn_split(DecAttnArgs a, SplitWs w) {
   if (tid == 0) wred[0] = (float)__hip_atomic_fetch_add(cnt + 2, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   __syncthreads();
   if ((int)wred[0] != S - 1) return;
-  for (int i = tid; i < GQ * HD; i += 256) {
-    const int q = i / HD, d = i % HD;
-    float t = 0.0f;
-    for (int sb = 0; sb < nsb; sb += 16) {
-      float sv[16];
-      ixt_xld16(gsb + ((size_t)q * g.nsb_max + sb) * HD + d, HD, min(16, nsb - sb), sv);
+  if constexpr (GQ * HD % 512 == 0) {       // two output elements per thread and round: their loads fly together
+    for (int i = tid; i < GQ * HD; i += 512) {
+      const int q0 = i / HD, d0 = i % HD, q1 = (i + 256) / HD, d1 = (i + 256) % HD;
+      float t0 = 0.0f, t1 = 0.0f;
+      for (int sb = 0; sb < nsb; sb += 16) {
+        float sv[16], su[16];
+        ixt_xld16x2(gsb + ((size_t)q0 * g.nsb_max + sb) * HD + d0, gsb + ((size_t)q1 * g.nsb_max + sb) * HD + d1, HD, min(16, nsb - sb), sv, su);
 #pragma unroll
-      for (int k = 0; k < 16; ++k) if (sb + k < nsb) t = t + sv[k];
+        for (int k = 0; k < 16; ++k) if (sb + k < nsb) { t0 = t0 + sv[k]; t1 = t1 + su[k]; }
+      }
+      a.out[xidx(r, (kvh * GQ + q0) * HD + d0, n_out)] = f2bf(t0);
+      a.out[xidx(r, (kvh * GQ + q1) * HD + d1, n_out)] = f2bf(t1);
     }
-    a.out[xidx(r, (kvh * GQ + q) * HD + d, n_out)] = f2bf(t);
+  } else {
+    for (int i = tid; i < GQ * HD; i += 256) {
+      const int q = i / HD, d = i % HD;
+      float t = 0.0f;
+      for (int sb = 0; sb < nsb; sb += 16) {
+        float sv[16];
+        ixt_xld16(gsb + ((size_t)q * g.nsb_max + sb) * HD + d, HD, min(16, nsb - sb), sv);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) if (sb + k < nsb) t = t + sv[k];
+      }
+      a.out[xidx(r, (kvh * GQ + q) * HD + d, n_out)] = f2bf(t);
+    }
   }
   if (tid < 3) __hip_atomic_store(cnt + tid, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -84,6 +84,7 @@ extern "C" int ixt_train_create(const ixt_train_config* c, ixt_trainer** out) {
   if (c->num_kv_heads <= 0 || c->num_query_heads % c->num_kv_heads) return t_set_err(IXT_ERR_INVALID, "train step: num_query_heads %% num_kv_heads != 0");
   if (c->head_dim % 8 || c->emb_dim % 8 || c->mlp_dim % 8 || c->vocab_size % 8 || c->seq_len % 8)
     return t_set_err(IXT_ERR_UNSUPPORTED, "train step: every dimension must be a multiple of 8");
+  if (c->emb_dim > 256 * TN_FPT) return t_set_err(IXT_ERR_UNSUPPORTED, "train step: emb_dim %d above %d (k_t_rmsnorm_bwd keeps a row block's scale gradients in registers)", c->emb_dim, 256 * TN_FPT);
   if (c->batch <= 0 || c->seq_len <= 0 || c->num_decoder_layers <= 0) return t_set_err(IXT_ERR_INVALID, "bad sizes");
   ixt_trainer* t = new ixt_trainer();
   t->cfg = *c;
@@ -255,7 +256,16 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     TTRY(gemm(st, t->xn_f + (long)t0 * E, E, 1, pb + t->o_logits, V, 1, t->logits, V, n, V, E, 0, 0));
     hipLaunchKernelGGL(k_t_xent, dim3(n), dim3(256), 0, st, t->logits, targets + t0, targets_segmentation + t0, t->dlog, t->row_loss + t0, V);
     // d xn_f = dlogits . W^T ; dW += xn_f^T . dlogits
-    TTRY(gemm(st, t->dlog, V, 1, pb + t->o_logits, 1, V, t->dxn + (long)t0 * E, E, n, E, V, 0, 0));
+    // (n x E outputs are only 256 tiles of 128 x 128 over K = V: the reduction is cut in KS parts -- batch dimension of the GEMM -- whose products
+    //  land in the idle score buffer and are added up in order; one part per CU took 8.8 ms per chunk at 253 TFLOP/s)
+    const int KS = (V % (4 * TG_BK) == 0 && V >= 65536 && (size_t)4 * n * E <= (size_t)B * H * S * S) ? 4 : 1;
+    if (KS > 1) {
+      TTRY(gemm(st, t->dlog, V, 1, pb + t->o_logits, 1, V, t->scores, E, n, E, V / KS, 0, 0, KS, 1, V / KS, 0, V / KS, 0, (long)n * E, 0));
+      hipLaunchKernelGGL(k_t_sum_parts, EW((long)n * E), t->scores, KS, (long)n * E, t->dxn + (long)t0 * E);
+      TLAUNCH();
+    } else {
+      TTRY(gemm(st, t->dlog, V, 1, pb + t->o_logits, 1, V, t->dxn + (long)t0 * E, E, n, E, V, 0, 0));
+    }
     TTRY(gemm(st, t->xn_f + (long)t0 * E, 1, E, t->dlog, V, 1, t->g + t->o_logits, V, E, V, n, 0, 1));
   }
   hipLaunchKernelGGL(k_t_reduce, dim3(1), dim3(256), 0, st, t->row_loss, (long)T, 0, loss_and_weights_dev, 0);
@@ -265,7 +275,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
   TLAUNCH();
   // ------------------------------------------------------------------ backward
   TCHK(hipMemsetAsync(t->dh, 0, sizeof(float) * (size_t)T * E, st));
-  hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3(T), dim3(256), 0, st, t->dxn, t->h_final, pb + t->o_fnorm, t->r_f, t->dh, t->g + t->o_fnorm, E);
+  hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3((T + TN_RPB - 1) / TN_RPB), dim3(256), 0, st, t->dxn, t->h_final, pb + t->o_fnorm, t->r_f, t->dh, t->g + t->o_fnorm, E, (long)T);
   for (int l = t->L - 1; l >= 0; --l) {
     LayerAct& a = t->act[l];
     const ixt_trainer::LOff& o = t->lo[l];
@@ -278,7 +288,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     TTRY(gemm(st, t->db, F, 1, pb + o.wi1, 1, F, t->dxn, E, T, E, F, 0, 1));
     TTRY(gemm(st, a.xn2, 1, E, t->da, F, 1, t->g + o.wi0, F, E, F, T, 0, 0));
     TTRY(gemm(st, a.xn2, 1, E, t->db, F, 1, t->g + o.wi1, F, E, F, T, 0, 0));
-    hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3(T), dim3(256), 0, st, t->dxn, a.h_mid, pb + o.ln2, a.r2, t->dh, t->g + o.ln2, E);
+    hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3((T + TN_RPB - 1) / TN_RPB), dim3(256), 0, st, t->dxn, a.h_mid, pb + o.ln2, a.r2, t->dh, t->g + o.ln2, E, (long)T);
     // attention: h_mid = h_in + out(ao)
     hipLaunchKernelGGL(k_t_f32_to_bf16, EW((long)T * E), t->dh, t->dy_bf, (long)T * E);
     TTRY(gemm(st, t->dy_bf, E, 1, pb + o.wo, 1, E, t->d_ao, QN, T, QN, E, 1, 0));                        // d ao = dy . Wo^T
@@ -316,7 +326,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     TTRY(gemm(st, a.xn1, 1, E, t->dq, QN, 1, t->g + o.wq, QN, E, QN, T, 0, 0));
     TTRY(gemm(st, a.xn1, 1, E, t->dk, KN, 1, t->g + o.wk, KN, E, KN, T, 0, 0));
     TTRY(gemm(st, a.xn1, 1, E, t->dv, KN, 1, t->g + o.wv, KN, E, KN, T, 0, 0));
-    hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3(T), dim3(256), 0, st, t->dxn, a.h_in, pb + o.ln1, a.r1, t->dh, t->g + o.ln1, E);
+    hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3((T + TN_RPB - 1) / TN_RPB), dim3(256), 0, st, t->dxn, a.h_in, pb + o.ln1, a.r1, t->dh, t->g + o.ln1, E, (long)T);
     TLAUNCH();
   }
   hipLaunchKernelGGL(k_t_embed_bwd, dim3((E + 255) / 256, T), dim3(256), 0, st, t->dh, inputs, t->g + t->o_emb, E, V);

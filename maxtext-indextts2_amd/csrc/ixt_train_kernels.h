@@ -184,23 +184,48 @@ __global__ __launch_bounds__(256) void k_t_rmsnorm_fwd(const bf16_t* __restrict_
   for (int e = threadIdx.x; e < E; e += 256) y[row * E + e] = f2bf(rbf(bf2f(x[row * E + e]) * r) * bf2f(scale[e]));
 }
 // backward: dy f32 [T][E] (the sum of the consumers' input gradients); dx (f32) is ADDED to dh (the residual-stream gradient);
-// dscale is accumulated by f32 atomics (one partial per block and feature group).
+// dscale: a block walks TN_RPB rows and keeps its features' partial sums in registers -- one f32 atomic per feature and BLOCK (one per feature
+// and row took 466 us per launch at 16384 x 2048: 2048 addresses under 33 M atomics).  grid = ceil(T / TN_RPB), block 256, E <= 256 TN_FPT.
+#define TN_RPB 16
+#define TN_FPT 16
 __global__ __launch_bounds__(256) void k_t_rmsnorm_bwd(const float* __restrict__ dy, const bf16_t* __restrict__ x, const bf16_t* __restrict__ scale,
-                                                       const float* __restrict__ rstd, float* __restrict__ dh, float* __restrict__ dscale, int E) {
+                                                       const float* __restrict__ rstd, float* __restrict__ dh, float* __restrict__ dscale, int E, long T) {
   __shared__ float red[4];
-  const long row = blockIdx.x;
-  const float r = rstd[row];
-  float s = 0.0f;
-  for (int e = threadIdx.x; e < E; e += 256) {
-    const float xh = bf2f(x[row * E + e]) * r;
-    s += dy[row * E + e] * bf2f(scale[e]) * xh;
+  float ds[TN_FPT];
+#pragma unroll
+  for (int i = 0; i < TN_FPT; ++i) ds[i] = 0.0f;
+  const long row0 = (long)blockIdx.x * TN_RPB;
+  for (long row = row0; row < row0 + TN_RPB && row < T; ++row) {
+    const float r = rstd[row];
+    float s = 0.0f;
+    for (int e = threadIdx.x; e < E; e += 256) {
+      const float xh = bf2f(x[row * E + e]) * r;
+      s += dy[row * E + e] * bf2f(scale[e]) * xh;
+    }
+    const float mean = t_block_sum(s, red) / (float)E;
+#pragma unroll
+    for (int i = 0; i < TN_FPT; ++i) {
+      const int e = threadIdx.x + i * 256;
+      if (e < E) {
+        const float xh = bf2f(x[row * E + e]) * r, gy = dy[row * E + e];
+        dh[row * E + e] += r * (gy * bf2f(scale[e]) - xh * mean);
+        ds[i] += gy * xh;
+      }
+    }
   }
-  const float mean = t_block_sum(s, red) / (float)E;
-  for (int e = threadIdx.x; e < E; e += 256) {
-    const float xh = bf2f(x[row * E + e]) * r, gy = dy[row * E + e];
-    dh[row * E + e] += r * (gy * bf2f(scale[e]) - xh * mean);
-    atomicAdd(dscale + e, gy * xh);
+#pragma unroll
+  for (int i = 0; i < TN_FPT; ++i) {
+    const int e = threadIdx.x + i * 256;
+    if (e < E) atomicAdd(dscale + e, ds[i]);
   }
+}
+// out[i] = parts[0][i] + parts[1][i] + ... (split-K partial products, in order)
+__global__ void k_t_sum_parts(const float* __restrict__ parts, int nparts, long n, float* __restrict__ out) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float t = parts[i];
+  for (int p = 1; p < nparts; ++p) t += parts[(long)p * n + i];
+  out[i] = t;
 }
 
 // RoPE (embeddings.py:277-315) on x bf16 [T][H][D] with per-token positions; INV: the transposed rotation (backward).  grid = (T, H), block D/2.
