@@ -33,6 +33,16 @@ def test_mixtral_batched_ragged(use_graph):
   run_pair(cfg, w, prompts, steps=36)
 
 
+@pytest.mark.parametrize("options", [{"moe_fused_gate": 0}, {"moe_route_blocks": 0}, {"small_attn_split": 0}, {"moe_mid_pairs": 2048}, {"moe_grouped": 0}])
+def test_mixtral_kernel_forms_agree_with_the_oracle(options):
+  """Every alternative form of a Mixtral step against the same oracle run: split-K wi + separate gate kernel, one-wave-per-expert router, one-launch
+  decode attention instead of the split one, 64-row whole-K expert dots for prefill-sized copy counts, every expert over all rows."""
+  cfg = _cfg(per_device_batch_size=3.0, pagedattn_num_pages=96)
+  w = H.synth.synth_weights(cfg, 4)
+  prompts = [(_prompt(cfg.vocab_size, 48, 300 + s), [48, 7, 29][s]) for s in range(3)]
+  run_pair(cfg, w, prompts, steps=12, options=options)
+
+
 def test_mixtral_chunked_prefill():
   cfg = _cfg(max_prefill_predict_length=16, per_device_batch_size=2.0, use_chunked_prefill=True, prefill_chunk_size=16)
   w = H.synth.synth_weights(cfg, 2)
