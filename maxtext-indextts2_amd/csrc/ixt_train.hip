@@ -185,8 +185,22 @@ extern "C" int ixt_train_refresh_bf16(ixt_trainer* t, void* stream) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launches
+// Scratch for split reductions (set by the step: a buffer that is idle while the layers' backward GEMMs run).
+static float* g_splitk_buf = nullptr;
+static size_t g_splitk_floats = 0;
 static int gemm(hipStream_t st, const bf16_t* A, long sam, long sak, const bf16_t* B, long sbk, long sbn, void* C, long scm, int M, int N, int K, int out_bf16,
                 int accumulate, int nb1 = 1, int nb2 = 1, long sab1 = 0, long sab2 = 0, long sbb1 = 0, long sbb2 = 0, long scb1 = 0, long scb2 = 0) {
+  // A weight gradient of few output tiles over a long reduction (2048 x 2048 over 16384 tokens: 256 tiles, one block per CU, 287 TFLOP/s): the
+  // reduction is cut in four batch parts whose products are added up in order (k_t_sum_parts).
+  constexpr int KS = 4;
+  if (!out_bf16 && !accumulate && nb1 * nb2 == 1 && scm == N && K >= 2048 && K % (KS * TG_BK) == 0 && (long)((N + 127) / 128) * ((M + 127) / 128) <= 256 &&
+      g_splitk_buf != nullptr && (size_t)KS * M * N <= g_splitk_floats) {
+    const int rc = gemm(st, A, sam, sak, B, sbk, sbn, g_splitk_buf, N, M, N, K / KS, 0, 0, KS, 1, (long)(K / KS) * sak, 0, (long)(K / KS) * sbk, 0, (long)M * N, 0);
+    if (rc != IXT_OK) return rc;
+    hipLaunchKernelGGL(k_t_sum_parts, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, st, g_splitk_buf, KS, (long)M * N, reinterpret_cast<float*>(C));
+    TLAUNCH();
+    return IXT_OK;
+  }
   TGemm g;
   g.A = A; g.sam = sam; g.sak = sak; g.sab1 = sab1; g.sab2 = sab2;
   g.B = B; g.sbk = sbk; g.sbn = sbn; g.sbb1 = sbb1; g.sbb2 = sbb2;
@@ -209,6 +223,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
   if (!t || !inputs || !positions || !segmentation || !targets || !targets_segmentation || !loss_and_weights_dev)
     return t_set_err(IXT_ERR_INVALID, "null argument");
   if (!t->p) return t_set_err(IXT_ERR_INVALID, "bind the parameter buffers first");
+  g_splitk_buf = nullptr; g_splitk_floats = 0;
   hipStream_t st = (hipStream_t)stream;
   const int E = t->E, H = t->H, D = t->D, F = t->F, V = t->V, S = t->S, T = t->T, QN = t->QN, B = t->B, KVH = t->KVH, G = t->G, KN = t->KN;
   const long HD = (long)H * D;
@@ -233,7 +248,8 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     for (int g = 0; g < G; ++g)
       TTRY(gemm(st, a.q + (long)g * D, HD, 1, a.k, 1, KN, t->scores + (long)g * S * S, S, S, S, D, 0, 0, B, KVH, (long)S * HD, (long)G * D, (long)S * KN, D,
                 (long)H * S * S, (long)G * S * S));
-    hipLaunchKernelGGL(k_t_softmax_fwd, dim3(S, B * H), dim3(256), 0, st, t->scores, segmentation, a.P, S, H);
+    if (S <= 256 * TS_MAXV) hipLaunchKernelGGL(k_t_softmax_fwd_reg, dim3(S, B * H), dim3(256), 0, st, t->scores, segmentation, a.P, S, H);
+    else hipLaunchKernelGGL(k_t_softmax_fwd, dim3(S, B * H), dim3(256), 0, st, t->scores, segmentation, a.P, S, H);
     for (int g = 0; g < G; ++g)
       TTRY(gemm(st, a.P + (long)g * S * S, S, 1, a.v, KN, 1, a.ao + (long)g * D, HD, S, D, S, 1, 0, B, KVH, (long)H * S * S, (long)G * S * S, (long)S * KN, D,
                 (long)S * HD, (long)G * D));
@@ -249,6 +265,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
     TLAUNCH();
   }
   hipLaunchKernelGGL(k_t_rmsnorm_fwd, dim3(T), dim3(256), 0, st, t->h_final, pb + t->o_fnorm, t->xn_f, t->r_f, E, eps);
+  g_splitk_buf = nullptr; g_splitk_floats = 0;          // (the logits buffer is in use below)
   // ------------------------------------------------------------------ logits, loss and their gradients, a chunk of rows at a time
   TCHK(hipMemsetAsync(t->dxn, 0, sizeof(float) * (size_t)T * E, st));
   for (int t0 = 0; t0 < T; t0 += t->Tc) {
@@ -274,6 +291,7 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
   hipLaunchKernelGGL(k_t_reduce, dim3(1), dim3(256), 0, st, t->row_loss, (long)T, 0, loss_and_weights_dev + 1, 0);
   TLAUNCH();
   // ------------------------------------------------------------------ backward
+  g_splitk_buf = t->logits; g_splitk_floats = (size_t)t->Tc * V;   // idle from here on: scratch of the split weight-gradient GEMMs
   TCHK(hipMemsetAsync(t->dh, 0, sizeof(float) * (size_t)T * E, st));
   hipLaunchKernelGGL(k_t_rmsnorm_bwd, dim3((T + TN_RPB - 1) / TN_RPB), dim3(256), 0, st, t->dxn, t->h_final, pb + t->o_fnorm, t->r_f, t->dh, t->g + t->o_fnorm, E, (long)T);
   for (int l = t->L - 1; l >= 0; --l) {
@@ -306,7 +324,8 @@ extern "C" int ixt_train_forward_backward(ixt_trainer* t, const int32_t* inputs,
                   (long)S * HD, (long)G * D, (long)S * KN, D));
       hipLaunchKernelGGL(k_t_f32_to_bf16, EW((long)T * KN), t->dvf, t->dv, (long)T * KN);
     }
-    hipLaunchKernelGGL(k_t_softmax_bwd, dim3(S, B * H), dim3(256), 0, st, t->scores, a.P, t->dS, S);
+    if (S <= 256 * TS_MAXV) hipLaunchKernelGGL(k_t_softmax_bwd_reg, dim3(S, B * H), dim3(256), 0, st, t->scores, a.P, t->dS, S);
+    else hipLaunchKernelGGL(k_t_softmax_bwd, dim3(S, B * H), dim3(256), 0, st, t->scores, a.P, t->dS, S);
     for (int g = 0; g < G; ++g)
       TTRY(gemm(st, t->dS + (long)g * S * S, S, 1, a.k, KN, 1, t->dq + (long)g * D, HD, S, D, S, 1, 0, B, KVH, (long)H * S * S, (long)G * S * S, (long)S * KN, D,
                 (long)S * HD, (long)G * D));

@@ -268,6 +268,44 @@ __global__ __launch_bounds__(256) void k_t_softmax_fwd(const float* __restrict__
     p[j] = on ? f2bf(ixt_exp(s[j] - m) / l) : (bf16_t)0;
   }
 }
+// The same row in ONE pass over memory (S <= 256 TS_MAXV): a thread's scores and segment tests stay in registers, every exponential is taken once.
+// Same values as the three-pass form bit for bit (same per-thread order of the partial sums); 1.70 -> see DESIGN.md section 9.
+#define TS_MAXV 16
+__global__ __launch_bounds__(256) void k_t_softmax_fwd_reg(const float* __restrict__ sc, const int32_t* __restrict__ seg, bf16_t* __restrict__ P, int S, int H) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const long bh = blockIdx.y, b = bh / H;
+  const float* s = sc + (bh * S + row) * S;
+  bf16_t* p = P + (bh * S + row) * S;
+  const int myseg = seg[b * S + row];
+  float v[TS_MAXV];
+  unsigned onmask = 0;
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < TS_MAXV; ++i) {
+    const int j = threadIdx.x + i * 256;
+    const bool on = j <= row && seg[b * S + min(j, S - 1)] == myseg;     // (row < S: j <= row is inside the row)
+    v[i] = on ? s[j] : -INFINITY;
+    if (on) { onmask |= 1u << i; m = fmaxf(m, v[i]); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float l = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TS_MAXV; ++i) {
+    if ((onmask >> i) & 1u) { v[i] = ixt_exp(v[i] - m); l += v[i]; } else v[i] = 0.0f;
+  }
+  l = t_block_sum(l, red);
+#pragma unroll
+  for (int i = 0; i < TS_MAXV; ++i) {
+    const int j = threadIdx.x + i * 256;
+    if (j < S) p[j] = ((onmask >> i) & 1u) ? f2bf(v[i] / l) : (bf16_t)0;
+  }
+}
 // dS = P o (dP - sum_j dP P), bf16 out (in place of nothing: separate buffer).  grid = (S, BH), block 256.
 __global__ __launch_bounds__(256) void k_t_softmax_bwd(const float* __restrict__ dP, const bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int S) {
   __shared__ float red[4];
@@ -276,6 +314,28 @@ __global__ __launch_bounds__(256) void k_t_softmax_bwd(const float* __restrict__
   for (int j = threadIdx.x; j < S; j += 256) s += dP[base + j] * bf2f(P[base + j]);
   const float dot = t_block_sum(s, red);
   for (int j = threadIdx.x; j < S; j += 256) { const float p = bf2f(P[base + j]); dS[base + j] = f2bf(p * (dP[base + j] - dot)); }
+}
+// one pass (S <= 256 TS_MAXV); columns beyond the row hold P = 0 (the causal mask): their dP is not read
+__global__ __launch_bounds__(256) void k_t_softmax_bwd_reg(const float* __restrict__ dP, const bf16_t* __restrict__ P, bf16_t* __restrict__ dS, int S) {
+  __shared__ float red[4];
+  const int row = blockIdx.x;
+  const long base = ((long)blockIdx.y * S + row) * S;
+  float g[TS_MAXV], pv[TS_MAXV];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < TS_MAXV; ++i) {
+    const int j = threadIdx.x + i * 256;
+    const bool in = j <= row;
+    pv[i] = in ? bf2f(P[base + j]) : 0.0f;
+    g[i] = in ? dP[base + j] : 0.0f;
+    s += g[i] * pv[i];
+  }
+  const float dot = t_block_sum(s, red);
+#pragma unroll
+  for (int i = 0; i < TS_MAXV; ++i) {
+    const int j = threadIdx.x + i * 256;
+    if (j < S) dS[base + j] = f2bf(pv[i] * (g[i] - dot));
+  }
 }
 
 // SwiGLU (linears.py:449-464) forward: act = bf16(bf16(a sg) b), sg = bf16(sigmoid(a)); backward through the unrounded formula.
